@@ -1,0 +1,62 @@
+"""Synthetic MIQP instances for tests and bench.py.
+
+`random_miqp` follows the generator recipe of the reference's benchmark script
+(/root/reference/examples/random_miqp/run_example.py:49,71-83): one `np.random.seed`, then per
+instance, in this RNG order, i_idx, Pt, q, A, u, l.  `scipy.sparse.random`'s sampling is
+scipy-version dependent, so instances are identified by `instance_digest` (a hash of the
+generated arrays), not by the seed alone.
+"""
+import hashlib
+
+import numpy as np
+import scipy.sparse as spa
+
+# BASELINE.json configs (n, m, p, density)
+CONFIGS = {
+    "cfg1": dict(n=50, m=100, p=10, density=0.7),
+    "cfg2": dict(n=500, m=1000, p=250, density=0.7),
+    "cfg5": dict(n=5000, m=10000, p=2500, density=0.01),
+}
+
+# settings dicts of the reference benchmark (run_example.py:98-116)
+BNB_SETTINGS = {"eps_int_feas": 1e-03, "max_iter_bb": 1000, "tree_explor_rule": 1,
+                "branching_rule": 0, "verbose": False, "print_interval": 1}
+QP_SETTINGS = {"eps_abs": 1e-03, "eps_rel": 1e-03, "eps_prim_inf": 1e-04, "verbose": False}
+
+
+def random_miqp(n, m, p, density=0.7, seed=0, reseed=True):
+    """One random MIQP  min .5 x'Px + q'x  s.t. l <= Ax <= u, x[i_idx] in {0,1}."""
+    if reseed:
+        np.random.seed(seed)
+    i_idx = np.random.choice(np.arange(0, n), p, replace=False)
+    Pt = spa.random(n, n, density=density)
+    P = spa.csc_matrix(Pt.dot(Pt.T))
+    q = np.random.randn(n)
+    A = spa.csc_matrix(spa.random(m, n, density=density))
+    u = 2 + np.random.rand(m)
+    l = -2 + np.random.rand(m)
+    i_l = np.zeros(p)
+    i_u = np.ones(p)
+    return dict(P=P, q=q, A=A, l=l, u=u, i_idx=i_idx, i_l=i_l, i_u=i_u)
+
+
+def instance_digest(prob):
+    h = hashlib.sha256()
+    for k in ("P", "A"):
+        M = spa.csc_matrix(prob[k])
+        M.sort_indices()
+        for a in (M.indptr, M.indices, M.data):
+            h.update(np.ascontiguousarray(a).tobytes())
+    for k in ("q", "l", "u", "i_idx", "i_l", "i_u"):
+        h.update(np.ascontiguousarray(prob[k]).tobytes())
+    return h.hexdigest()[:16]
+
+
+def extended(prob):
+    """(A_ext, l_ext, u_ext): integer bounds appended as identity rows, the layout of
+    /root/reference/miosqp/data.py:5-33 (rows m .. m+p-1 hold x[i_idx])."""
+    A = spa.csc_matrix(prob["A"])
+    n = A.shape[1]
+    I = spa.identity(n, format="csc")[prob["i_idx"], :]
+    A_ext = spa.vstack([A, I]).tocsc()
+    return A_ext, np.append(prob["l"], prob["i_l"]), np.append(prob["u"], prob["i_u"])
