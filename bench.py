@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Headline benchmark: ADMM iterations/s (+ B&B nodes/s) on random_miqp n=500 m=1000 p=250.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the random MIQP of the reference's own generator recipe
+(/root/reference/examples/random_miqp/run_example.py:71-83, seed 0, density 0.7) at n=500,
+m=1000, 250 binaries, explored by the branch-and-bound host logic one node at a time per GPU with
+the reference's settings (run_example.py:98-116).  One "step" = one wave = `--wave` node
+relaxations per rank (default 1: node-at-a-time) followed by the incumbent exchange.  Inputs
+(factor, matrices) are resident in HBM before the timed region; the per-node vectors (l, u, x0,
+y0: 34 KB) are part of the path and travel inside it.  N > 1 shards the open leaves over the
+ranks (miosqp_amd/dist.py), one process per GPU, RCCL only for the incumbent: weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+KERNELS = ["k_panel_fwd", "k_tail_fwd", "k_tail_bwd", "k_panel_bwd"]
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def cpu_baseline(prob, budget_s):
+    """The CPU oracle ("port": own restatement, NOT the real OSQP which is absent) on the same tree,
+    one thread, bounded to about `budget_s` seconds."""
+    from miosqp_amd import bnb, dist, problems
+    from oracle import oracle
+    st = dict(problems.BNB_SETTINGS)
+    st["max_iter_bb"] = 10 ** 9
+    model = bnb.MIOSQP(backend=oracle)
+    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"],
+                prob["i_u"], st, dict(problems.QP_SETTINGS))
+    srch = dist.ShardedSearch(model)
+    t0 = time.time()
+    while time.time() - t0 < budget_s and model.work.leaves:
+        srch.step(1)
+    dt = time.time() - t0
+    return dict(value=srch.iters / dt, unit="ADMM iter/s", cores=1, kind="port",
+                nodes_per_s=srch.nodes / dt,
+                sample="first %d nodes (%d ADMM iterations, %.1f s) of the same tree, oracle/qp_oracle.c "
+                       "single thread; real OSQP is not installed" % (srch.nodes, srch.iters, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--wave", type=int, default=1, help="node relaxations per rank per step")
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg5"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from miosqp_amd import bnb, dist, problems
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the relaxation engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group(backend="nccl", device_id=dev)
+        comm = dist.TorchComm(dev)
+    else:
+        comm = dist.LocalComm()
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    cfg = problems.CONFIGS[args.config]
+    prob = problems.random_miqp(seed=args.seed, **cfg)
+    st = dict(problems.BNB_SETTINGS)
+    st["max_iter_bb"] = 10 ** 9  # fixed node budget comes from --steps, not from the tree
+    qs = dict(problems.QP_SETTINGS)
+    qs["device"] = local_rank
+    model = bnb.MIOSQP()
+    t_setup = time.time()
+    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"],
+                prob["i_u"], st, qs)
+    t_setup = time.time() - t_setup
+    eng = model.work.solver
+    srch = dist.ShardedSearch(model, comm)
+    # identical on every rank: open enough leaves to deal at least one to each rank
+    srch.expand_until(max(2 * world, 2))
+    if world > 1:
+        srch.deal()
+
+    def sync():
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        srch.step(args.wave)
+    sync()
+    eng.loop_stats(reset=True)
+    n0, i0 = srch.nodes, srch.iters
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        srch.step(args.wave)
+    sync()
+    dt = time.perf_counter() - t0
+    loop_ms, loop_iters = eng.loop_stats()
+    tot = comm.sum([srch.iters - i0, srch.nodes - n0, dt])
+    dt_max = dt
+    if world > 1:
+        import torch.distributed as td
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt_max = float(tmax.item())
+    iters, nodes = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        fs = eng.factor_stats()
+        kern = []
+        for k in range(4):
+            us, by = eng.time_kernel(k, 300)
+            kern.append(dict(kernel=KERNELS[k], usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
+        it_us, it_bytes = eng.time_kernel(4, 100)
+        dom = max(kern, key=lambda d: d["usec"])
+        roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=None,
+                    bytes_per_launch=dom["bytes"], usec_per_launch=dom["usec"], kernels=kern,
+                    iteration=dict(bytes=fs["bytes_per_iter"],
+                                   usec_in_timed_region=round(1e3 * loop_ms / max(1, loop_iters), 3),
+                                   usec_back_to_back=round(it_us, 3),
+                                   achieved=round(fs["bytes_per_iter"] * loop_iters / max(1e-9, loop_ms) * 1e-6, 1),
+                                   frac=round(fs["bytes_per_iter"] * loop_iters / max(1e-9, loop_ms) * 1e-6 /
+                                              HBM_PEAK_GBS, 4)),
+                    timing="HIP events on the engine's stream")
+        out = dict(metric="ADMM iterations/s (random_miqp n=%d m=%d p=%d, node-at-a-time B&B)" %
+                          (cfg["n"], cfg["m"], cfg["p"]),
+                   value=round(iters / dt_max, 1), unit="ADMM iter/s", n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=round(1e3 * dt_max / args.steps, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                   nodes_per_s=round(nodes / dt_max, 2), iters_per_node=round(iters / max(1.0, nodes), 1),
+                   config=dict(workload="BASELINE configs[1]: random_miqp n=%d m=%d p=%d density %.2f seed %d, "
+                                        "%d node(s) per rank per step, leaves sharded over %d GPU(s)" %
+                                        (cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed, args.wave, world),
+                               instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
+                               qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3)),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * miosqp_amd.h -- C ABI of the MI355X QP-relaxation engine (libmiosqp_hip.so).
+ *
+ * Drop-in boundary for ONE path of miOSQP: the relaxation solve that Node.solve() triggers.
+ * The reference reaches that path through five Python calls on one shared `osqp.OSQP` object;
+ * each entry point below names the reference call it replaces.  Plain pointers and sizes only;
+ * every array argument is copied during the call (the reference keeps mutating its numpy
+ * arrays afterwards: /root/reference/miosqp/data.py:120,126), outputs are written into
+ * caller-owned buffers.  All functions return 0 on success, a negative MIOSQP_E* code on error,
+ * or a positive value where documented.  Not re-entrant per handle (the reference is
+ * single-threaded: one solver object mutated in place, workspace.py:63).
+ *
+ * Matrices: CSC, 32-bit indices, fp64 values (scipy's native layout, README.md:31 of the
+ * reference).  P may be the full symmetric matrix or its upper triangle; only entries with
+ * row <= col are read.  A is the EXTENDED constraint matrix [A; I[i_idx,:]] built by
+ * /root/reference/miosqp/data.py:5-33, M = m + n_int rows.
+ */
+#ifndef MIOSQP_AMD_H
+#define MIOSQP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* solve outcome (info.status_val); values follow OSQP 0.6.x, looked up by name through
+ * miosqp_qp_constant() exactly as the reference does with osqp.constant(name)
+ * (/root/reference/miosqp/node.py:88,128-129; workspace.py:294-295,403-404,419). */
+#define MIOSQP_QP_SOLVED 1
+#define MIOSQP_QP_MAX_ITER_REACHED (-2)
+#define MIOSQP_QP_PRIMAL_INFEASIBLE (-3)
+#define MIOSQP_QP_DUAL_INFEASIBLE (-4)
+#define MIOSQP_QP_UNSOLVED (-10)
+
+/* error codes */
+#define MIOSQP_EARG (-1)      /* bad argument (NULL, negative size, crossed bounds at setup) */
+#define MIOSQP_EHIP (-2)      /* a HIP runtime call failed; see miosqp_qp_last_error() */
+#define MIOSQP_EFACTOR (-3)   /* KKT factorisation broke down (non-convex P?) */
+#define MIOSQP_ENODEV (-4)    /* no usable gfx950 device */
+#define MIOSQP_EBOUNDS 1      /* update_bounds: some l[i] > u[i]; nothing was changed */
+
+/* Solver parameters = the keyword arguments the reference forwards verbatim to
+ * osqp.OSQP.setup (/root/reference/miosqp/workspace.py:67-68).  The reference's examples set
+ * only eps_abs, eps_rel, eps_prim_inf, verbose (examples/random_miqp/run_example.py:113-116);
+ * everything else is this table (DESIGN.md "frozen spec"). rho is ONE scalar for all rows and
+ * is never adapted, so the factor is shared by every branch-and-bound node. */
+typedef struct miosqp_qp_settings {
+  double rho;          /* 0.1  */
+  double sigma;        /* 1e-6 */
+  double alpha;        /* 1.6  */
+  double eps_abs;      /* 1e-3 */
+  double eps_rel;      /* 1e-3 */
+  double eps_prim_inf; /* 1e-4 */
+  double eps_dual_inf; /* 1e-4 */
+  int32_t max_iter;          /* 4000 */
+  int32_t scaling;           /* 10 Ruiz passes, 0 = off */
+  int32_t check_termination; /* 25: residuals are tested every this many iterations */
+  int32_t warm_start;        /* 1: solve() continues from the stored iterates */
+  int32_t device;            /* HIP device ordinal; -1 = current device */
+  int32_t max_batch;         /* capacity of miosqp_qp_solve_batch (>= 1) */
+  int32_t reserved[6];
+} miosqp_qp_settings;
+
+/* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus
+ * residuals and the fused node epilogue. */
+typedef struct miosqp_qp_info {
+  int32_t status_val; /* node.py:111 */
+  int32_t iter;       /* node.py:118 */
+  double run_time;    /* node.py:121: host wall seconds of this solve call */
+  double obj_val;     /* relaxation objective at the returned x (unused by the reference) */
+  double pri_res;
+  double dua_res;
+  double device_time; /* seconds between HIP events around the device work of this call */
+  double lower;       /* solve_node/solve_batch only: objective at the clamped x (node.py:143) */
+} miosqp_qp_info;
+
+typedef struct miosqp_qp_engine miosqp_qp_engine;
+
+/* fills *s with the defaults tabulated above */
+int miosqp_qp_default_settings(miosqp_qp_settings *s);
+
+/* osqp.constant(name) -- /root/reference/miosqp/node.py:88.  Unknown name -> 0. */
+int miosqp_qp_constant(const char *name);
+
+/* osqp.OSQP().setup(P, q, A, l, u, **qp_settings) -- /root/reference/miosqp/workspace.py:63-68.
+ * Scales the problem, factorises the KKT matrix once and places factor + matrices in HBM. */
+int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M,
+                    const int32_t *P_colptr, const int32_t *P_rowidx, const double *P_val,
+                    const int32_t *A_colptr, const int32_t *A_rowidx, const double *A_val,
+                    const double *q, const double *l, const double *u,
+                    const miosqp_qp_settings *settings);
+
+/* solver.update(l=l, u=u) -- /root/reference/miosqp/node.py:102.  l, u: M doubles each. */
+int miosqp_qp_update_bounds(miosqp_qp_engine *e, const double *l, const double *u);
+
+/* solver.update(q=q) -- /root/reference/miosqp/solver.py:183-185.  q: n doubles. */
+int miosqp_qp_update_lin_cost(miosqp_qp_engine *e, const double *q);
+
+/* solver.warm_start(x=x, y=y) -- /root/reference/miosqp/node.py:105.  x: n, y: M doubles. */
+int miosqp_qp_warm_start(miosqp_qp_engine *e, const double *x, const double *y);
+
+/* results = solver.solve() -- /root/reference/miosqp/node.py:108-125.
+ * x_out: n doubles, y_out: M doubles (fresh copies), info filled. */
+int miosqp_qp_solve(miosqp_qp_engine *e, double *x_out, double *y_out, miosqp_qp_info *info);
+
+/* Declares which rows of A are the integer-bound rows so that the node epilogue can run on
+ * the device: rows m .. m+n_int-1 of A are I[i_idx,:] (/root/reference/miosqp/data.py:19-29).
+ * i_idx: n_int variable indices.  Must be called before solve_node / solve_batch. */
+int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t *i_idx,
+                               int32_t m_orig);
+
+/* Whole body of Node.solve() in one call -- /root/reference/miosqp/node.py:96-143:
+ * update(l,u) -> warm_start(x0,y0) -> solve -> x[i_idx] clamped into [l[-n_int:], u[-n_int:]]
+ * (node.py:131-136) -> lower = .5 x'Px + q'x at the clamped x (node.py:143, data.py:99-103).
+ * For infeasible outcomes x/y hold the certificate as solve() returns it and lower is NaN. */
+int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u,
+                         const double *x0, const double *y0, double *x_out, double *y_out,
+                         miosqp_qp_info *info);
+
+/* B independent nodes sharing the factor (leaves of Workspace.leaves,
+ * /root/reference/miosqp/workspace.py:83), node-major arrays: l,u,y0,y_out [B][M];
+ * x0,x_out [B][n]; info [B].  Each node's result equals what solve_node returns for it. */
+int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const double *u,
+                          const double *x0, const double *y0, double *x_out, double *y_out,
+                          miosqp_qp_info *info);
+
+/* frees device and host memory */
+int miosqp_qp_cleanup(miosqp_qp_engine *e);
+
+/* ---- introspection used by bench.py and the parity tests (not part of the reference API) -- */
+
+/* human-readable text of the last failure on this thread */
+const char *miosqp_qp_last_error(void);
+
+/* scaled iterates after running exactly k ADMM iterations from the current state with the
+ * termination test disabled (iterate-level parity against the oracle). x: n, z,y: M. */
+int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z, double *y);
+
+/* D (n), E (M), c of the Ruiz equilibration */
+int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
+
+/* sizes of the factor: out[0]=nnz(L) strict (panel + tail), out[1]=nnz panel, out[2]=tail order,
+ * out[3]=algorithmic bytes per ADMM iteration (SURVEY.md sec. 8d formula), out[4..7] reserved */
+int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
+
+/* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's
+ * own stream and returns the mean duration in microseconds in *usec and the kernel's
+ * algorithmic bytes per launch in *bytes.  which: 0 panel-forward, 1 tail-forward,
+ * 2 tail-backward, 3 panel-backward+update, 4 one whole ADMM iteration (all four). */
+int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, double *usec,
+                          double *bytes);
+
+/* Device time spent in the ADMM loop since the last reset, measured with HIP events recorded on
+ * the engine's stream around every chunk (check_termination iterations + one termination test)
+ * of every solve: *ms = total milliseconds, *iters = ADMM iterations executed in them. */
+int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIOSQP_AMD_H */

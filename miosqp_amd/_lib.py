@@ -1,0 +1,83 @@
+"""ctypes binding of libmiosqp_hip.so (the C ABI declared in include/miosqp_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing or cannot be loaded this
+module raises, and `OSQP.setup` raises when no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmiosqp_hip.so")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+
+
+class Settings(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf", "eps_dual_inf")] + \
+               [(k, C.c_int32) for k in ("max_iter", "scaling", "check_termination", "warm_start",
+                                         "device", "max_batch")] + \
+               [("reserved", C.c_int32 * 6)]
+
+
+class Info(C.Structure):
+    _fields_ = [("status_val", C.c_int32), ("iter", C.c_int32), ("run_time", C.c_double),
+                ("obj_val", C.c_double), ("pri_res", C.c_double), ("dua_res", C.c_double),
+                ("device_time", C.c_double), ("lower", C.c_double)]
+
+
+# every symbol include/miosqp_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "miosqp_qp_default_settings": (C.c_int, [C.POINTER(Settings)]),
+    "miosqp_qp_constant": (C.c_int, [C.c_char_p]),
+    "miosqp_qp_setup": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, ip, ip, dp, ip, ip,
+                                  dp, dp, dp, dp, C.POINTER(Settings)]),
+    "miosqp_qp_update_bounds": (C.c_int, [C.c_void_p, dp, dp]),
+    "miosqp_qp_update_lin_cost": (C.c_int, [C.c_void_p, dp]),
+    "miosqp_qp_warm_start": (C.c_int, [C.c_void_p, dp, dp]),
+    "miosqp_qp_solve": (C.c_int, [C.c_void_p, dp, dp, C.POINTER(Info)]),
+    "miosqp_qp_set_integer_rows": (C.c_int, [C.c_void_p, C.c_int32, ip, C.c_int32]),
+    "miosqp_qp_solve_node": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, C.POINTER(Info)]),
+    "miosqp_qp_solve_batch": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp,
+                                        C.POINTER(Info)]),
+    "miosqp_qp_cleanup": (C.c_int, [C.c_void_p]),
+    "miosqp_qp_last_error": (C.c_char_p, []),
+    "miosqp_qp_debug_iterate": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp]),
+    "miosqp_qp_get_scaling": (C.c_int, [C.c_void_p, dp, dp, dp]),
+    "miosqp_qp_get_factor_stats": (C.c_int, [C.c_void_p, i64p]),
+    "miosqp_qp_get_loop_stats": (C.c_int, [C.c_void_p, dp, i64p, C.c_int32]),
+    "miosqp_qp_time_kernel": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, dp, dp]),
+}
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C miosqp_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def last_error():
+    msg = load().miosqp_qp_last_error()
+    return msg.decode() if msg else ""
+
+
+def as_d(a):
+    return a.ctypes.data_as(dp)
+
+
+def as_i(a):
+    return a.ctypes.data_as(ip)

@@ -1,0 +1,317 @@
+// Host-side one-time preparation: equilibration and block LDL^T factor.  See factor.hpp.
+#include "factor.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <functional>
+#include <thread>
+
+namespace miosqp {
+
+namespace {
+
+constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;
+
+inline double clamp_scaling(double v) {
+  if (v < kMinScaling) v = 1.0;
+  if (v > kMaxScaling) v = kMaxScaling;
+  return v;
+}
+
+// dynamic-chunk parallel loop over [0, count)
+void parallel_chunks(int64_t count, int64_t work_per_item, const std::function<void(int64_t)> &fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nthreads = (int)std::min<int64_t>(hw ? hw : 1, 32);
+  if (nthreads <= 1 || count < 2 || count * work_per_item < (int64_t)1 << 22) {
+    for (int64_t i = 0; i < count; i++) fn(i);
+    return;
+  }
+  std::atomic<int64_t> next(0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; t++)
+    pool.emplace_back([&]() {
+      for (;;) {
+        int64_t i = next.fetch_add(1);
+        if (i >= count) break;
+        fn(i);
+      }
+    });
+  for (auto &th : pool) th.join();
+}
+
+// column inf-norms of a symmetric matrix given by its upper triangle
+void sym_col_norms(int n, const std::vector<int> &Pp, const std::vector<int> &Pi,
+                   const std::vector<double> &Px, std::vector<double> &out) {
+  std::fill(out.begin(), out.end(), 0.0);
+  for (int j = 0; j < n; j++)
+    for (int p = Pp[j]; p < Pp[j + 1]; p++) {
+      double a = std::fabs(Px[p]);
+      out[j] = std::max(out[j], a);
+      out[Pi[p]] = std::max(out[Pi[p]], a);
+    }
+}
+
+// rows -> padded compressed rows
+struct Triplet {
+  int col;
+  double v0, v1;
+};
+
+void pack_rows(int rows, int cols, std::vector<std::vector<Triplet>> &r, PCsr &out,
+               std::vector<double> *second) {
+  out.rows = rows;
+  out.cols = cols;
+  out.ptr.assign(rows + 1, 0);
+  out.nnz = 0;
+  int64_t total = 0;
+  for (int i = 0; i < rows; i++) {
+    out.nnz += (int64_t)r[i].size();
+    total += ((int64_t)r[i].size() + 1) & ~(int64_t)1;
+  }
+  out.idx.assign(total, 0);
+  out.val.assign(total, 0.0);
+  if (second) second->assign(total, 0.0);
+  int64_t k = 0;
+  for (int i = 0; i < rows; i++) {
+    out.ptr[i] = (int)k;
+    std::sort(r[i].begin(), r[i].end(), [](const Triplet &a, const Triplet &b) { return a.col < b.col; });
+    for (const Triplet &t : r[i]) {
+      out.idx[k] = t.col;
+      out.val[k] = t.v0;
+      if (second) (*second)[k] = t.v1;
+      k++;
+    }
+    if (k & 1) {  // pad: zero value, repeat a valid column
+      out.idx[k] = r[i].empty() ? 0 : r[i].back().col;
+      k++;
+    }
+  }
+  out.ptr[rows] = (int)k;
+}
+
+}  // namespace
+
+void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
+                   const int32_t *Ap, const int32_t *Ai, const double *Ax, const double *q,
+                   int passes, Scaled &s) {
+  s.n = n;
+  s.M = M;
+  s.Pp.assign(n + 1, 0);
+  s.Pi.clear();
+  s.Px.clear();
+  for (int j = 0; j < n; j++) {
+    s.Pp[j] = (int)s.Pi.size();
+    for (int p = Pp[j]; p < Pp[j + 1]; p++)
+      if (Pi[p] <= j) {
+        s.Pi.push_back(Pi[p]);
+        s.Px.push_back(Px[p]);
+      }
+  }
+  s.Pp[n] = (int)s.Pi.size();
+  s.Ap.assign(Ap, Ap + n + 1);
+  s.Ai.assign(Ai, Ai + Ap[n]);
+  s.Ax.assign(Ax, Ax + Ap[n]);
+  s.q.assign(q, q + n);
+  s.D.assign(n, 1.0);
+  s.E.assign(M, 1.0);
+  s.c = 1.0;
+  std::vector<double> dt(n), et(M);
+  for (int pass = 0; pass < passes; pass++) {
+    sym_col_norms(n, s.Pp, s.Pi, s.Px, dt);
+    std::fill(et.begin(), et.end(), 0.0);
+    for (int j = 0; j < n; j++)
+      for (int p = s.Ap[j]; p < s.Ap[j + 1]; p++) {
+        double a = std::fabs(s.Ax[p]);
+        dt[j] = std::max(dt[j], a);
+        et[s.Ai[p]] = std::max(et[s.Ai[p]], a);
+      }
+    for (int j = 0; j < n; j++) dt[j] = 1.0 / std::sqrt(clamp_scaling(dt[j]));
+    for (int i = 0; i < M; i++) et[i] = 1.0 / std::sqrt(clamp_scaling(et[i]));
+    for (int j = 0; j < n; j++)
+      for (int p = s.Pp[j]; p < s.Pp[j + 1]; p++) s.Px[p] *= dt[j] * dt[s.Pi[p]];
+    for (int j = 0; j < n; j++)
+      for (int p = s.Ap[j]; p < s.Ap[j + 1]; p++) s.Ax[p] *= dt[j] * et[s.Ai[p]];
+    for (int j = 0; j < n; j++) {
+      s.q[j] *= dt[j];
+      s.D[j] *= dt[j];
+    }
+    for (int i = 0; i < M; i++) s.E[i] *= et[i];
+    // cost normalisation
+    sym_col_norms(n, s.Pp, s.Pi, s.Px, dt);
+    double mean = 0;
+    for (int j = 0; j < n; j++) mean += dt[j];
+    mean /= n;
+    double nq = 0;
+    for (int j = 0; j < n; j++) nq = std::max(nq, std::fabs(s.q[j]));
+    double ct = 1.0 / clamp_scaling(std::max(mean, clamp_scaling(nq)));
+    for (double &v : s.Px) v *= ct;
+    for (double &v : s.q) v *= ct;
+    s.c *= ct;
+  }
+  s.Dinv.resize(n);
+  s.Einv.resize(M);
+  for (int j = 0; j < n; j++) s.Dinv[j] = 1.0 / s.D[j];
+  for (int i = 0; i < M; i++) s.Einv[i] = 1.0 / s.E[i];
+  s.cinv = 1.0 / s.c;
+}
+
+bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
+                  const double *Px_raw, double rho, double sigma, Factor &f, std::string &err) {
+  const int n = s.n, M = s.M;
+  f.n = n;
+  f.M = M;
+  f.rho = rho;
+  f.sigma = sigma;
+  f.ld = (n + 7) & ~7;
+  const int ld = f.ld;
+
+  // ---- panel: rows of Abar^T (per variable) and rows of Abar (per constraint) ----------
+  {
+    std::vector<std::vector<Triplet>> byvar(n), bycon(M);
+    for (int i = 0; i < n; i++) byvar[i].reserve(s.Ap[i + 1] - s.Ap[i]);
+    for (int i = 0; i < n; i++)
+      for (int p = s.Ap[i]; p < s.Ap[i + 1]; p++) {
+        int j = s.Ai[p];
+        double a = s.Ax[p];
+        byvar[i].push_back({j, -rho * a, a});
+        bycon[j].push_back({i, -rho * a, a});
+      }
+    pack_rows(n, M, byvar, f.panel_by_var, &f.At_val);
+    pack_rows(M, n, bycon, f.panel_by_con, &f.A_val);
+    f.nnz_panel = f.panel_by_var.nnz;
+  }
+  // ---- symmetric matrices by row ----------------------------------------------------------
+  {
+    std::vector<std::vector<Triplet>> rows(n);
+    for (int j = 0; j < n; j++)
+      for (int p = s.Pp[j]; p < s.Pp[j + 1]; p++) {
+        int i = s.Pi[p];
+        rows[i].push_back({j, s.Px[p], 0});
+        if (i != j) rows[j].push_back({i, s.Px[p], 0});
+      }
+    pack_rows(n, n, rows, f.Pbar, nullptr);
+    for (auto &r : rows) r.clear();
+    for (int j = 0; j < n; j++)
+      for (int p = Pp_raw[j]; p < Pp_raw[j + 1]; p++) {
+        int i = Pi_raw[p];
+        if (i > j) continue;
+        rows[i].push_back({j, Px_raw[p], 0});
+        if (i != j) rows[j].push_back({i, Px_raw[p], 0});
+      }
+    pack_rows(n, n, rows, f.Praw, nullptr);
+  }
+  // ---- Schur complement S = Pbar + sigma I + rho Abar^T Abar (dense, lower, row-major) -----
+  std::vector<double> S((size_t)n * ld, 0.0);
+  for (int j = 0; j < n; j++)
+    for (int p = s.Pp[j]; p < s.Pp[j + 1]; p++) S[(size_t)j * ld + s.Pi[p]] += s.Px[p];  // (j >= i)
+  for (int j = 0; j < n; j++) S[(size_t)j * ld + j] += sigma;
+  {
+    // accumulate rho * a_r a_r^T over constraint rows r, parallel over output rows of S:
+    // S[i1][i2] += rho * sum_r A[r][i1] A[r][i2].  Use column form: for variable i1 (col of A)
+    // scatter into a dense accumulator through the rows it touches.
+    const PCsr &R = f.panel_by_con;  // rows of Abar with A_val
+    parallel_chunks(n, (int64_t)f.nnz_panel, [&](int64_t i1) {
+      double *out = &S[(size_t)i1 * ld];
+      for (int p = s.Ap[i1]; p < s.Ap[i1 + 1]; p++) {
+        int r = s.Ai[p];
+        double w = rho * s.Ax[p];
+        for (int k = R.ptr[r]; k < R.ptr[r + 1]; k++) {
+          int i2 = R.idx[k];
+          if (i2 > i1) break;  // row sorted by column; padding repeats the last column
+          out[i2] += w * f.A_val[k];
+        }
+      }
+    });
+    // padding entries carry value 0, so a repeated last column adds nothing
+  }
+  // ---- blocked right-looking LDL^T of S (in place: strict lower = L22, diag = D22) ------
+  std::vector<double> d(n);
+  const int nb = 64;
+  std::vector<double> W;  // scaled block columns
+  bool ok = true;
+  for (int jb = 0; jb < n && ok; jb += nb) {
+    int je = std::min(n, jb + nb), w = je - jb;
+    // diagonal block, unblocked
+    for (int j = jb; j < je; j++) {
+      double *Sj = &S[(size_t)j * ld];
+      double dj = Sj[j];
+      for (int k = jb; k < j; k++) dj -= Sj[k] * Sj[k] * d[k];
+      if (!(dj > 0.0) || !std::isfinite(dj)) {
+        ok = false;
+        err = "KKT factorisation: non-positive pivot in the reduced Hessian (P not PSD?)";
+        break;
+      }
+      d[j] = dj;
+      for (int i = j + 1; i < je; i++) {
+        double *Si = &S[(size_t)i * ld];
+        double v = Si[j];
+        for (int k = jb; k < j; k++) v -= Si[k] * d[k] * Sj[k];
+        Si[j] = v / dj;
+      }
+    }
+    if (!ok) break;
+    if (je >= n) break;
+    // panel below the diagonal block
+    parallel_chunks(n - je, (int64_t)w * w, [&](int64_t ii) {
+      double *Si = &S[(size_t)(je + ii) * ld];
+      for (int j = jb; j < je; j++) {
+        const double *Sj = &S[(size_t)j * ld];
+        double v = Si[j];
+        for (int k = jb; k < j; k++) v -= Si[k] * d[k] * Sj[k];
+        Si[j] = v / d[j];
+      }
+    });
+    // trailing update: S[i][j] -= sum_k L[i][k] d[k] L[j][k],  je <= j <= i
+    W.assign((size_t)(n - je) * nb, 0.0);
+    for (int i = je; i < n; i++)
+      for (int k = 0; k < w; k++) W[(size_t)(i - je) * nb + k] = S[(size_t)i * ld + jb + k] * d[jb + k];
+    parallel_chunks(n - je, (int64_t)(n - je) * w / 2 + 1, [&](int64_t ii) {
+      int i = je + (int)ii;
+      double *Si = &S[(size_t)i * ld];
+      const double *Wi = &W[(size_t)ii * nb];
+      for (int j = je; j <= i; j++) {
+        const double *Lj = &S[(size_t)j * ld + jb];
+        double acc = 0;
+        for (int k = 0; k < w; k++) acc += Wi[k] * Lj[k];
+        Si[j] -= acc;
+      }
+    });
+  }
+  if (!ok) return false;
+  f.d2inv.resize(n);
+  for (int j = 0; j < n; j++) f.d2inv[j] = 1.0 / d[j];
+  f.nnz_tail = (int64_t)n * (n - 1) / 2;
+  // ---- Linv = L22^-1 (unit lower).  Columns are independent: X[i][j] depends only on
+  //      X[k][j], k < i, so column chunks are computed in parallel with no synchronisation.
+  f.Linv.assign((size_t)n * ld, 0.0);
+  {
+    const int cw = 16;
+    int nchunks = (n + cw - 1) / cw;
+    double *X = f.Linv.data();
+    parallel_chunks(nchunks, (int64_t)n * n / 4 + 1, [&](int64_t ch) {
+      int c0 = (int)ch * cw, c1 = std::min(n, c0 + cw);
+      double acc[cw];
+      for (int i = c0 + 1; i < n; i++) {
+        const double *Li = &S[(size_t)i * ld];
+        int hi = std::min(c1, i);  // columns c0 .. hi-1 of row i are below the diagonal
+        for (int t = 0; t < cw; t++) acc[t] = 0;
+        // X[i][j] = -L[i][j] - sum_{k=j+1}^{i-1} L[i][k] X[k][j]
+        for (int k = c0 + 1; k < i; k++) {
+          double lik = Li[k];
+          const double *Xk = &X[(size_t)k * ld];
+          int jh = std::min(hi, k);  // X[k][j] nonzero (strict lower) only for j < k
+          for (int j = c0; j < jh; j++) acc[j - c0] += lik * Xk[j];
+        }
+        double *Xi = &X[(size_t)i * ld];
+        for (int j = c0; j < hi; j++) Xi[j] = -Li[j] - acc[j - c0];
+      }
+    });
+  }
+  f.LinvT.assign((size_t)n * ld, 0.0);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) f.LinvT[(size_t)j * ld + i] = f.Linv[(size_t)i * ld + j];
+  return true;
+}
+
+}  // namespace miosqp

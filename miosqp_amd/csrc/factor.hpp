@@ -1,0 +1,74 @@
+// Host-side (CPU, one-time) preparation of the relaxation engine: Ruiz equilibration and the
+// block LDL^T factor of the quasi-definite KKT matrix.  See DESIGN.md "Factor layout".
+//
+// Stands in for what osqp.OSQP().setup() does once per MIQP
+// (/root/reference/miosqp/workspace.py:63-68).  With the elimination order "constraint rows
+// first, variables last" (what a minimum-degree ordering yields on these problems, SURVEY.md
+// sec. 0.5) the factor  K = L D L^T  of
+//
+//        K = [ -1/rho I    A  ]        L = [  I     0  ]     D = [ -1/rho I   0  ]
+//            [   A^T   P+sigma I ]         [ L21   L22 ]         [    0      D22 ]
+//
+// is   L21 = -rho A^T  (sparse, pattern of A^T: the "panel"),
+//      L22 D22 L22^T = P + sigma I + rho A^T A  (dense trailing triangle: the "tail").
+// The tail is kept as its pre-inverted triangular factor  Linv = L22^-1  (unit lower, same
+// size and sparsity as L22) so that both triangular sweeps over it are row-parallel.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace miosqp {
+
+// Row-major compressed rows, every row padded to an even number of entries (value 0, a valid
+// column) so that a lane can fetch two entries with one 16-byte + one 8-byte load.
+struct PCsr {
+  int rows = 0, cols = 0;
+  std::vector<int> ptr;   // rows + 1, all even
+  std::vector<int> idx;
+  std::vector<double> val;
+  int64_t nnz = 0;  // true (unpadded) entry count
+};
+
+struct Scaled {
+  int n = 0, M = 0;
+  std::vector<double> D, E, Dinv, Einv;
+  double c = 1.0, cinv = 1.0;
+  // scaled data
+  std::vector<int> Pp, Pi;  // upper triangle, CSC
+  std::vector<double> Px;
+  std::vector<int> Ap, Ai;  // CSC
+  std::vector<double> Ax;
+  std::vector<double> q;  // scaled linear cost
+};
+
+struct Factor {
+  int n = 0, M = 0, ld = 0;
+  double rho = 0, sigma = 0;
+  // panel L21, stored twice: by tail row (variable i: entries over constraints j) for the
+  // forward sweep, by head row (constraint j: entries over variables i) for the backward sweep.
+  PCsr panel_by_var;  // n rows x M cols, values L21[i][j] = -rho * Abar[j][i]
+  PCsr panel_by_con;  // M rows x n cols, values L21[i][j] seen from row j
+  // same patterns with the plain scaled matrix values (residual checks, warm start)
+  std::vector<double> At_val;  // aligned with panel_by_var.idx   (Abar^T rows)
+  std::vector<double> A_val;   // aligned with panel_by_con.idx   (Abar rows)
+  // tail
+  std::vector<double> Linv;   // n x ld row-major, strict lower part of L22^-1 (diag = 1 implied)
+  std::vector<double> LinvT;  // n x ld row-major, strict upper part = Linv^T
+  std::vector<double> d2inv;  // 1 / D22
+  // symmetric matrices by row
+  PCsr Pbar;  // scaled P, full symmetric
+  PCsr Praw;  // unscaled P, full symmetric (node objective, data.py:99-103)
+  int64_t nnz_panel = 0, nnz_tail = 0;
+};
+
+// Ruiz equilibration + cost normalisation (OSQP paper sec. 5.1).  P: CSC, only row<=col read.
+void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
+                   const int32_t *Ap, const int32_t *Ai, const double *Ax, const double *q,
+                   int passes, Scaled &out);
+
+// Builds the factor; returns false with `err` set when D22 loses positivity.
+bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
+                  const double *Px_raw, double rho, double sigma, Factor &f, std::string &err);
+
+}  // namespace miosqp

@@ -1,0 +1,216 @@
+"""`osqp`-shaped front of the HIP relaxation engine.
+
+Presents exactly the surface the reference's branch-and-bound layer uses on its `osqp` module
+(SURVEY.md sec. 8b):
+
+    osqp.OSQP().setup(P, q, A, l, u, **qp_settings)      /root/reference/miosqp/workspace.py:63-68
+    solver.update(l=, u=) / solver.update(q=)            node.py:102 / solver.py:185
+    solver.warm_start(x=, y=)                            node.py:105
+    solver.solve() -> .x .y .info.status_val .iter .run_time          node.py:108-125
+    osqp.constant(name)                                  node.py:88,128-129
+
+plus the fused / batched extensions `solve_node`, `solve_batch`.  Everything numeric happens in
+libmiosqp_hip.so through the C ABI of include/miosqp_amd.h; this file only marshals arrays.
+"""
+import ctypes as C
+import types
+
+import numpy as np
+import scipy.sparse as spa
+
+from miosqp_amd import _lib
+
+# accepted spellings from older OSQP releases (the reference's own fixtures use them:
+# /root/reference/max_iter_examples/*.pickle carry 'eps_inf' and 'polishing')
+_ALIASES = {"eps_inf": "eps_prim_inf", "eps_unb": "eps_dual_inf",
+            "early_terminate_interval": "check_termination"}
+# accepted and ignored: no effect on the iteration
+_IGNORED = {"verbose", "polish", "polishing", "linsys_solver", "time_limit", "scaled_termination",
+            "delta", "polish_refine_iter", "early_terminate"}
+
+
+def constant(name):
+    """osqp.constant(name)."""
+    v = _lib.load().miosqp_qp_constant(name.encode())
+    if v == 0:
+        raise ValueError("Constant %s not found" % name)
+    return v
+
+
+def default_settings():
+    s = _lib.Settings()
+    _lib.load().miosqp_qp_default_settings(C.byref(s))
+    return s
+
+
+def _settings_from_kwargs(kw):
+    s = default_settings()
+    for k, v in kw.items():
+        k = _ALIASES.get(k, k)
+        if k in _IGNORED:
+            continue
+        if k == "adaptive_rho":
+            if v:
+                raise ValueError("adaptive_rho is not supported: rho is one fixed scalar so that "
+                                 "the KKT factor is shared by every node (DESIGN.md)")
+            continue
+        if k not in dict(s._fields_) or k == "reserved":
+            raise TypeError("setup() got an unexpected setting %r" % k)
+        setattr(s, k, v)
+    return s
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, _lib.last_error()))
+    return rc
+
+
+def _f64(a, size, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != (size,):
+        raise ValueError("%s must have %d entries" % (name, size))
+    return a
+
+
+class OSQP(object):
+    def __init__(self):
+        self._h = None
+        self._lib = _lib.load()
+        self.n = self.m = 0
+
+    # -- setup -----------------------------------------------------------------------------
+    def setup(self, P=None, q=None, A=None, l=None, u=None, **settings):
+        if self._h is not None:
+            raise RuntimeError("setup() called twice")
+        P = spa.csc_matrix(P)
+        A = spa.csc_matrix(A)
+        P.sort_indices()
+        A.sort_indices()
+        n, m = A.shape[1], A.shape[0]
+        if P.shape != (n, n):
+            raise ValueError("P must be %d x %d" % (n, n))
+        s = _settings_from_kwargs(settings)
+        arrs = [np.ascontiguousarray(P.indptr, dtype=np.int32),
+                np.ascontiguousarray(P.indices, dtype=np.int32),
+                np.ascontiguousarray(P.data, dtype=np.float64),
+                np.ascontiguousarray(A.indptr, dtype=np.int32),
+                np.ascontiguousarray(A.indices, dtype=np.int32),
+                np.ascontiguousarray(A.data, dtype=np.float64),
+                _f64(q, n, "q"), _f64(l, m, "l"), _f64(u, m, "u")]
+        if np.any(arrs[7] > arrs[8]):
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+        h = C.c_void_p()
+        rc = self._lib.miosqp_qp_setup(C.byref(h), n, m, _lib.as_i(arrs[0]), _lib.as_i(arrs[1]),
+                                       _lib.as_d(arrs[2]), _lib.as_i(arrs[3]), _lib.as_i(arrs[4]),
+                                       _lib.as_d(arrs[5]), _lib.as_d(arrs[6]), _lib.as_d(arrs[7]),
+                                       _lib.as_d(arrs[8]), C.byref(s))
+        _check(rc, "setup")
+        self._h, self.n, self.m, self.settings = h, n, m, s
+
+    def set_integer_rows(self, i_idx, m_orig):
+        ii = np.ascontiguousarray(i_idx, dtype=np.int32)
+        _check(self._lib.miosqp_qp_set_integer_rows(self._h, len(ii), _lib.as_i(ii), int(m_orig)),
+               "set_integer_rows")
+
+    # -- the reference's four calls ------------------------------------------------------------
+    def update(self, q=None, l=None, u=None):
+        if q is not None:
+            _check(self._lib.miosqp_qp_update_lin_cost(self._h, _lib.as_d(_f64(q, self.n, "q"))),
+                   "update(q)")
+        if l is not None or u is not None:
+            if l is None or u is None:
+                raise ValueError("update() needs both l and u")
+            l, u = _f64(l, self.m, "l"), _f64(u, self.m, "u")
+            rc = _check(self._lib.miosqp_qp_update_bounds(self._h, _lib.as_d(l), _lib.as_d(u)),
+                        "update(l,u)")
+            if rc == 1:
+                raise ValueError("Lower bound must be lower than or equal to upper bound")
+
+    def warm_start(self, x=None, y=None):
+        if x is None or y is None:
+            raise ValueError("warm_start() needs both x and y")
+        _check(self._lib.miosqp_qp_warm_start(self._h, _lib.as_d(_f64(x, self.n, "x")),
+                                              _lib.as_d(_f64(y, self.m, "y"))), "warm_start")
+
+    def solve(self):
+        x, y, info = np.empty(self.n), np.empty(self.m), _lib.Info()
+        _check(self._lib.miosqp_qp_solve(self._h, _lib.as_d(x), _lib.as_d(y), C.byref(info)), "solve")
+        return types.SimpleNamespace(x=x, y=y, info=info)
+
+    # -- fused / batched extensions ------------------------------------------------------------
+    def solve_node(self, l, u, x0, y0):
+        """Whole body of Node.solve() (node.py:96-143) in one device round trip."""
+        l, u = _f64(l, self.m, "l"), _f64(u, self.m, "u")
+        x0, y0 = _f64(x0, self.n, "x0"), _f64(y0, self.m, "y0")
+        x, y, info = np.empty(self.n), np.empty(self.m), _lib.Info()
+        rc = _check(self._lib.miosqp_qp_solve_node(self._h, _lib.as_d(l), _lib.as_d(u), _lib.as_d(x0),
+                                                   _lib.as_d(y0), _lib.as_d(x), _lib.as_d(y),
+                                                   C.byref(info)), "solve_node")
+        if rc == 1:
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+        lower = None if np.isnan(info.lower) else info.lower
+        return types.SimpleNamespace(x=x, y=y, status_val=info.status_val, iter=info.iter,
+                                     run_time=info.run_time, lower=lower, info=info)
+
+    def solve_batch(self, l, u, x0, y0):
+        """B independent nodes sharing the factor; arrays are [B, .]."""
+        l = np.ascontiguousarray(l, dtype=np.float64)
+        B = l.shape[0]
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(B, self.m)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n)
+        y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(B, self.m)
+        x, y = np.empty((B, self.n)), np.empty((B, self.m))
+        infos = (_lib.Info * B)()
+        rc = _check(self._lib.miosqp_qp_solve_batch(self._h, B, _lib.as_d(l), _lib.as_d(u),
+                                                    _lib.as_d(x0), _lib.as_d(y0), _lib.as_d(x),
+                                                    _lib.as_d(y), infos), "solve_batch")
+        if rc == 1:
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+        return types.SimpleNamespace(
+            x=x, y=y, status_val=np.array([i.status_val for i in infos]),
+            iter=np.array([i.iter for i in infos]), lower=np.array([i.lower for i in infos]),
+            run_time=np.array([i.run_time for i in infos]), infos=infos)
+
+    # -- introspection ------------------------------------------------------------------------
+    def debug_iterate(self, k):
+        x, z, y = np.empty(self.n), np.empty(self.m), np.empty(self.m)
+        _check(self._lib.miosqp_qp_debug_iterate(self._h, k, _lib.as_d(x), _lib.as_d(z), _lib.as_d(y)),
+               "debug_iterate")
+        return x, z, y
+
+    def scaling(self):
+        D, E, c = np.empty(self.n), np.empty(self.m), C.c_double()
+        _check(self._lib.miosqp_qp_get_scaling(self._h, _lib.as_d(D), _lib.as_d(E), C.byref(c)),
+               "get_scaling")
+        return D, E, c.value
+
+    def factor_stats(self):
+        out = np.zeros(8, dtype=np.int64)
+        _check(self._lib.miosqp_qp_get_factor_stats(self._h, out.ctypes.data_as(_lib.i64p)),
+               "get_factor_stats")
+        return dict(nnz_L=int(out[0]), nnz_panel=int(out[1]), tail_order=int(out[2]),
+                    bytes_per_iter=int(out[3]), tpr=(int(out[4]), int(out[5]), int(out[6])))
+
+    def loop_stats(self, reset=False):
+        ms, it = C.c_double(), C.c_int64()
+        _check(self._lib.miosqp_qp_get_loop_stats(self._h, C.byref(ms), C.byref(it), int(reset)),
+               "get_loop_stats")
+        return ms.value, it.value
+
+    def time_kernel(self, which, reps=200):
+        us, by = C.c_double(), C.c_double()
+        _check(self._lib.miosqp_qp_time_kernel(self._h, which, reps, C.byref(us), C.byref(by)),
+               "time_kernel")
+        return us.value, by.value
+
+    def close(self):
+        if self._h is not None:
+            self._lib.miosqp_qp_cleanup(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

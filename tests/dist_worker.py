@@ -1,0 +1,46 @@
+"""Worker for tests/test_dist_gloo.py: one rank of a world_size-2 sharded tree search on CPU
+(gloo), with the CPU oracle standing in for the GPU engine (test infrastructure)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from miosqp_amd import bnb, dist, problems  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def main():
+    out_path, n, m, p, seed, per_rank = sys.argv[1], *map(int, sys.argv[2:7])
+    td.init_process_group(backend="gloo")
+    comm = dist.TorchComm(torch.device("cpu"))
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    model = bnb.MIOSQP(backend=oracle)
+    st = dict(problems.BNB_SETTINGS)
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
+                dict(problems.QP_SETTINGS))
+    s = dist.ShardedSearch(model, comm)
+    s.expand_until(2 * comm.world)
+    before = len(model.work.leaves)
+    s.deal()
+    mine = len(model.work.leaves)
+    waves = s.run(nodes_per_rank=per_rank)
+    tot = comm.sum([s.nodes, s.iters, mine])
+    w = model.work
+    rec = dict(rank=comm.rank, upper=w.upper_glob, x=list(map(float, w.x)), status=w.status, waves=waves,
+               nodes_total=float(tot[0]), iters_total=float(tot[1]), dealt_total=float(tot[2]),
+               leaves_before_deal=before)
+    with open("%s.%d" % (out_path, comm.rank), "w") as f:
+        json.dump(rec, f)
+    td.barrier()
+    td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""The C-ABI library loads on a CPU-only machine and exports every symbol the header declares."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "miosqp_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(miosqp_qp_[a-z_]+)\s*\(", txt)))
+
+
+def test_library_exports_header_symbols():
+    from miosqp_amd import _lib
+    lib = _lib.load()
+    names = _header_functions()
+    assert len(names) >= 16
+    for nm in names:
+        assert hasattr(lib, nm), nm
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_constants_and_defaults_without_gpu():
+    from miosqp_amd import qp
+    assert qp.constant("OSQP_SOLVED") == 1
+    assert qp.constant("OSQP_MAX_ITER_REACHED") == -2
+    assert qp.constant("OSQP_PRIMAL_INFEASIBLE") == -3
+    assert qp.constant("OSQP_DUAL_INFEASIBLE") == -4
+    assert qp.constant("OSQP_UNSOLVED") == -10
+    with pytest.raises(ValueError):
+        qp.constant("OSQP_NOPE")
+    s = qp.default_settings()
+    assert (s.rho, s.sigma, s.alpha, s.max_iter, s.scaling, s.check_termination) == (0.1, 1e-6, 1.6, 4000, 10, 25)
+
+
+def test_settings_validation_without_gpu():
+    from miosqp_amd import qp
+    with pytest.raises(ValueError):
+        qp._settings_from_kwargs({"adaptive_rho": True})
+    with pytest.raises(TypeError):
+        qp._settings_from_kwargs({"no_such_setting": 1})
+    s = qp._settings_from_kwargs({"eps_inf": 1e-5, "polishing": False, "verbose": False, "rho": 0.3})
+    assert s.eps_prim_inf == 1e-5 and s.rho == 0.3
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    from miosqp_amd import bnb, problems
+    pr = problems.random_miqp(10, 5, 2, seed=0)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        bnb.MIOSQP().setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"],
+                           pr["i_u"], dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "miosqp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# tests pass the CPU oracle", "").lower() or \
+                    f in ("bnb.py",), (dirpath, f)

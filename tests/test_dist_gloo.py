@@ -1,0 +1,69 @@
+"""Multi-process path (leaf sharding + incumbent exchange) on CPU: gloo, world_size 2.
+
+The GPU engine is replaced by the CPU oracle (test infrastructure); what is under test is
+miosqp_amd/dist.py: dealing, per-rank exploration, all-gather/broadcast of the incumbent,
+pruning against the global bound, termination when every rank runs dry.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from miosqp_amd import bnb, dist, problems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n,m,p,seed,per_rank", [(20, 100, 10, 3, 1), (30, 150, 15, 4, 3)])
+def test_two_ranks_find_the_same_optimum(tmp_path, oracle_mod, n, m, p, seed, per_rank):
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(m), str(p), str(seed), str(per_rank)]
+    subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=600)
+    recs = [json.load(open("%s.%d" % (out, r))) for r in range(2)]
+    # single-process reference run of the same host logic
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    model = bnb.MIOSQP(backend=oracle_mod)
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    res = model.solve()
+    assert res.status == bnb.MI_SOLVED
+    for r in recs:
+        assert r["status"] == bnb.MI_SOLVED
+        assert abs(r["upper"] - recs[0]["upper"]) == 0.0  # both ranks hold the same incumbent
+        np.testing.assert_array_equal(r["x"], recs[0]["x"])
+        # same optimum as the sequential search, to the relaxation tolerance
+        assert abs(r["upper"] - res.upper_glob) <= 1e-3 * max(1.0, abs(res.upper_glob))
+        ii = pr["i_idx"]
+        np.testing.assert_array_equal(np.asarray(r["x"])[ii], res.x[ii])
+    assert recs[0]["dealt_total"] == recs[0]["leaves_before_deal"]  # every leaf dealt exactly once
+    assert recs[0]["nodes_total"] >= 1
+
+
+def test_local_comm_is_the_sequential_search(oracle_mod):
+    pr = problems.random_miqp(20, 100, 10, seed=3)
+    a = bnb.MIOSQP(backend=oracle_mod)
+    b = bnb.MIOSQP(backend=oracle_mod)
+    for mdl in (a, b):
+        mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                  dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    ra = a.solve()
+    s = dist.ShardedSearch(b)
+    s.run(nodes_per_rank=1)
+    assert b.work.status == ra.status and b.work.upper_glob == ra.upper_glob
+    np.testing.assert_array_equal(b.work.x, ra.x)
+    assert s.nodes == a.work.iter_num - 1 and s.iters == a.work.osqp_iter
