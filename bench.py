@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-width", type=int, default=256,
+                    help="extra leg: leaves per batched wave (BASELINE configs[2]); 0 = skip")
+    ap.add_argument("--batch-waves", type=int, default=3)
     args = ap.parse_args()
 
     import torch
@@ -87,6 +90,7 @@ def main():
     st["max_iter_bb"] = 10 ** 9  # fixed node budget comes from --steps, not from the tree
     qs = dict(problems.QP_SETTINGS)
     qs["device"] = local_rank
+    qs["max_batch"] = max(64, args.batch_width)
     model = bnb.MIOSQP()
     t_setup = time.time()
     model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"],
@@ -123,6 +127,31 @@ def main():
         dt_max = float(tmax.item())
     iters, nodes = float(tot[0]), float(tot[1])
 
+    # ---- extra leg (BASELINE configs[2]): the same tree, waves of `batch_width` leaves per rank in
+    #      ONE batched device call each (not part of `value`) --------------------------------------
+    batched = None
+    if args.batch_width > 0:
+        srch.expand_until(args.batch_width)
+        srch.step_batched(args.batch_width)  # warm-up wave: graph capture, allocation
+        sync()
+        eng.batch_stats(reset=True)
+        n1, i1 = srch.nodes, srch.iters
+        t1 = time.perf_counter()
+        for _ in range(args.batch_waves):
+            srch.step_batched(args.batch_width)
+        sync()
+        dtb = time.perf_counter() - t1
+        bms, bit, bnode = eng.batch_stats()
+        totb = comm.sum([srch.iters - i1, srch.nodes - n1])
+        if world > 1:
+            tb = torch.tensor([dtb], dtype=torch.float64, device=dev)
+            td.all_reduce(tb, op=td.ReduceOp.MAX)
+            dtb = float(tb.item())
+        batched = dict(wave=args.batch_width, waves=args.batch_waves, nodes=float(totb[1]),
+                       node_iters_per_s=round(float(totb[0]) / dtb, 1), nodes_per_s=round(float(totb[1]) / dtb, 2),
+                       lockstep_iters=bit, device_us_per_lockstep_iter=round(1e3 * bms / max(1, bit), 2),
+                       device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
+
     if rank == 0:
         fs = eng.factor_stats()
         kern = []
@@ -153,6 +182,14 @@ def main():
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
                                qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3)),
                    roofline=roof)
+        if batched is not None:
+            bk = []
+            for k in range(4):
+                us, by = eng.time_kernel(10 + k, 30)
+                bk.append(dict(kernel="kb_" + KERNELS[k][2:], usec=round(us, 2), bytes=by,
+                               gbs=round(by / us * 1e-3, 1)))
+            batched["kernels"] = bk
+            out["batched"] = batched
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
         print(json.dumps(out))

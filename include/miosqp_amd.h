@@ -147,7 +147,8 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
 /* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's
  * own stream and returns the mean duration in microseconds in *usec and the kernel's
  * algorithmic bytes per launch in *bytes.  which: 0 panel-forward, 1 tail-forward,
- * 2 tail-backward, 3 panel-backward+update, 4 one whole ADMM iteration (all four). */
+ * 2 tail-backward, 3 panel-backward+update, 4 one whole ADMM iteration (all four);
+ * 10..14 the same for the batched kernels at full batch capacity (after a solve_batch). */
 int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, double *usec,
                           double *bytes);
 
@@ -155,6 +156,11 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
  * the engine's stream around every chunk (check_termination iterations + one termination test)
  * of every solve: *ms = total milliseconds, *iters = ADMM iterations executed in them. */
 int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, int32_t reset);
+
+/* Same for solve_batch: *ms device milliseconds in batched chunks, *batch_iters lock-step
+ * iterations executed, *node_iters = sum over those iterations of the columns still iterating. */
+int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters,
+                              int64_t *node_iters, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -254,6 +254,21 @@ class Workspace(object):
         xr[self.data.i_idx] = np.round(x[self.data.i_idx])
         return xr
 
+    def solve_wave(self, leaves):
+        """Relaxations of several open leaves at once.  With the HIP engine the wave is ONE
+        batched device call sharing the factor (`solve_batch`); every leaf ends up exactly as
+        its own Node.solve() would leave it."""
+        if len(leaves) > 1 and hasattr(self.solver, 'solve_batch'):
+            r = self.solver.solve_batch(np.stack([lf.l for lf in leaves]), np.stack([lf.u for lf in leaves]),
+                                        np.stack([lf.x for lf in leaves]), np.stack([lf.y for lf in leaves]))
+            for k, lf in enumerate(leaves):
+                lower = None if np.isnan(r.lower[k]) else float(r.lower[k])
+                lf._absorb(int(r.status_val[k]), int(r.iter[k]), float(r.run_time[k]), r.x[k].copy(),
+                           r.y[k].copy(), lower)
+        else:
+            for lf in leaves:
+                lf.solve()
+
     def prune(self):
         """Drop leaves whose bound exceeds the incumbent, with the reference's traversal:
         workspace.py:278-280 removes from the list it is iterating, so the element following

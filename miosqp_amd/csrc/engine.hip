@@ -52,6 +52,7 @@ void set_err(const char *what, hipError_t e, const char *file, int line) {
 
 struct Ctrl {
   int done, status, iter, pad;
+  int B, ndone, pad3[2];  // batched mode: active columns, columns already decided
   double pri_res, dua_res, obj_val, lower;
   double nrm_dy, nrm_dx;  // certificate normalisers
   double pad2[2];
@@ -83,6 +84,15 @@ struct Dev {
   // staging: raw (unscaled) inputs and outputs
   double *raw_l, *raw_u, *raw_x, *raw_y, *out_x, *out_y;
   Ctrl *ctrl;
+  // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
+  int Bs;  // column stride, multiple of 64
+  double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
+  double *b_sm, *b_sn;      // 8 x M x Bs, 4 x n x Bs
+  double *b_xfin, *b_yfin;  // unscaled answers, batch-fastest
+  double *b_raw;            // node-major staging in:  l[B][M] | u[B][M] | x0[B][n] | y0[B][M]
+  double *b_out;            // node-major staging out: x[B][n] | y[B][M]
+  int *c_done, *c_status, *c_iter;
+  double *c_pri, *c_dua, *c_obj, *c_lower;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -340,71 +350,93 @@ __device__ __forceinline__ double block_sum(double v, double *lds) {
   return r;
 }
 
-// one workgroup: all norms, all sums, the decision
-__global__ __launch_bounds__(1024) void k_check_decide(Dev d, int iters_in_chunk) {
+// The termination decision from the reduced quantities (OSQP paper sec. 3.4); shared by the
+// single-node and the batched path.  Returns 0 (keep iterating) or a final status.
+struct Norms {
+  double pri, nAx, nz, nEv, amax_u, amin_l, dua, nPx, nAty, nq, nPdx, nAtv, ndx, lhs, qdx, xPx, qx;
+};
+__device__ __forceinline__ int decide_status(const Dev &d, const Norms &v, double &obj) {
+  obj = d.cinv * (0.5 * v.xPx + v.qx);
+  const double eps_pri = d.eps_abs + d.eps_rel * fmax(v.nAx, v.nz);
+  const double eps_dua = d.eps_abs + d.eps_rel * d.cinv * fmax(fmax(v.nPx, v.nAty), v.nq);
+  const bool pri_ok = (d.M == 0) || (v.pri < eps_pri);
+  const bool dua_ok = v.dua < eps_dua;
+  bool pinf = false, dinf = false;
+  if (!pri_ok && v.nEv > QP_DIVISION_TOL && v.lhs < -d.eps_pinf * v.nEv) pinf = v.nAtv < d.eps_pinf * v.nEv;
+  if (!dua_ok && v.ndx > QP_DIVISION_TOL && v.qdx < -d.c * d.eps_dinf * v.ndx &&
+      v.nPdx < d.c * d.eps_dinf * v.ndx)
+    dinf = !(v.amax_u > d.eps_dinf * v.ndx) && !(v.amin_l < -d.eps_dinf * v.ndx);
+  if (pri_ok && dua_ok) return MIOSQP_QP_SOLVED;
+  if (pinf) { obj = QP_INFTY; return MIOSQP_QP_PRIMAL_INFEASIBLE; }
+  if (dinf) { obj = -QP_INFTY; return MIOSQP_QP_DUAL_INFEASIBLE; }
+  return 0;
+}
+
+constexpr int NQ = 17, NQ_MAX = 13;  // quantities 0..12 reduce with max, 13..16 with +
+
+// one workgroup (4 waves): all norms and sums in ONE pass (two barriers), then the decision
+__global__ __launch_bounds__(256) void k_check_decide(Dev d, int iters_in_chunk) {
   if (d.ctrl->done) return;
-  __shared__ double lds[16];
+  __shared__ double part[NQ][4];
+  __shared__ double res[NQ];
   const int n = d.n, M = d.M, tid = threadIdx.x;
-  double pri = 0, nAx = 0, nz = 0, nEv = 0, lhs = 0, amax_u = -1.7e308, amin_l = 1.7e308;
-  for (int j = tid; j < M; j += 1024) {
-    pri = fmax(pri, fabs(d.sm[0 * M + j]));
-    nAx = fmax(nAx, fabs(d.sm[1 * M + j]));
-    nz = fmax(nz, fabs(d.sm[2 * M + j]));
-    nEv = fmax(nEv, fabs(d.sm[4 * M + j]));
-    lhs += d.sm[5 * M + j];
-    amax_u = fmax(amax_u, d.sm[6 * M + j]);
-    amin_l = fmin(amin_l, d.sm[7 * M + j]);
+  double v[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = 0.0;
+  v[4] = -1.7e308;
+  v[5] = -1.7e308;
+  for (int j = tid; j < M; j += 256) {
+    v[0] = fmax(v[0], fabs(d.sm[0 * M + j]));
+    v[1] = fmax(v[1], fabs(d.sm[1 * M + j]));
+    v[2] = fmax(v[2], fabs(d.sm[2 * M + j]));
+    v[3] = fmax(v[3], fabs(d.sm[4 * M + j]));
+    v[4] = fmax(v[4], d.sm[6 * M + j]);
+    v[5] = fmax(v[5], -d.sm[7 * M + j]);
+    v[13] += d.sm[5 * M + j];
   }
-  double dua = 0, nPx = 0, nAty = 0, nq = 0, nPdx = 0, nAtv = 0, ndx = 0, qdx = 0, xPx = 0, qx = 0;
-  for (int i = tid; i < n; i += 1024) {
+  for (int i = tid; i < n; i += 256) {
     const double di = d.Dinv[i], px = d.sn[0 * n + i], aty = d.sn[2 * n + i], q = d.q[i], x = d.x[i],
                  dx = d.dx[i];
-    dua = fmax(dua, fabs(di * (px + q + aty)));
-    nPx = fmax(nPx, fabs(di * px));
-    nAty = fmax(nAty, fabs(di * aty));
-    nq = fmax(nq, fabs(di * q));
-    nPdx = fmax(nPdx, fabs(d.sn[1 * n + i]));
-    nAtv = fmax(nAtv, fabs(d.sn[3 * n + i]));
-    ndx = fmax(ndx, fabs(d.D[i] * dx));
-    qdx += q * dx;
-    xPx += x * px;
-    qx += q * x;
+    v[6] = fmax(v[6], fabs(di * (px + q + aty)));
+    v[7] = fmax(v[7], fabs(di * px));
+    v[8] = fmax(v[8], fabs(di * aty));
+    v[9] = fmax(v[9], fabs(di * q));
+    v[10] = fmax(v[10], fabs(d.sn[1 * n + i]));
+    v[11] = fmax(v[11], fabs(d.sn[3 * n + i]));
+    v[12] = fmax(v[12], fabs(d.D[i] * dx));
+    v[14] += q * dx;
+    v[15] += x * px;
+    v[16] += q * x;
   }
-  pri = block_max(pri, lds);
-  nAx = block_max(nAx, lds);
-  nz = block_max(nz, lds);
-  nEv = block_max(nEv, lds);
-  lhs = block_sum(lhs, lds);
-  amax_u = block_max(amax_u, lds);
-  amin_l = -block_max(-amin_l, lds);
-  dua = block_max(dua, lds) * d.cinv;
-  nPx = block_max(nPx, lds);
-  nAty = block_max(nAty, lds);
-  nq = block_max(nq, lds);
-  nPdx = block_max(nPdx, lds);
-  nAtv = block_max(nAtv, lds);
-  ndx = block_max(ndx, lds);
-  qdx = block_sum(qdx, lds);
-  xPx = block_sum(xPx, lds);
-  qx = block_sum(qx, lds);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const double o = __shfl_xor(v[q], off, 64);
+      v[q] = q < NQ_MAX ? fmax(v[q], o) : v[q] + o;
+    }
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) part[q][tid >> 6] = v[q];
+  }
+  __syncthreads();
+  if (tid < NQ) {
+    double r = part[tid][0];
+    for (int w = 1; w < 4; w++) r = tid < NQ_MAX ? fmax(r, part[tid][w]) : r + part[tid][w];
+    res[tid] = r;
+  }
+  __syncthreads();
   if (tid != 0) return;
+  Norms nm{res[0], res[1], res[2], res[3], res[4], -res[5], res[6] * d.cinv, res[7], res[8], res[9], res[10],
+           res[11], res[12], res[13], res[14], res[15], res[16]};
   Ctrl *c = d.ctrl;
+  double obj;
+  const int st = decide_status(d, nm, obj);
   c->iter += iters_in_chunk;
-  c->pri_res = pri;
-  c->dua_res = dua;
-  c->obj_val = d.cinv * (0.5 * xPx + qx);
-  const double eps_pri = d.eps_abs + d.eps_rel * fmax(nAx, nz);
-  const double eps_dua = d.eps_abs + d.eps_rel * d.cinv * fmax(fmax(nPx, nAty), nq);
-  const bool pri_ok = (M == 0) || (pri < eps_pri);
-  const bool dua_ok = dua < eps_dua;
-  bool pinf = false, dinf = false;
-  if (!pri_ok && nEv > QP_DIVISION_TOL && lhs < -d.eps_pinf * nEv) pinf = nAtv < d.eps_pinf * nEv;
-  if (!dua_ok && ndx > QP_DIVISION_TOL && qdx < -d.c * d.eps_dinf * ndx && nPdx < d.c * d.eps_dinf * ndx)
-    dinf = !(amax_u > d.eps_dinf * ndx) && !(amin_l < -d.eps_dinf * ndx);
-  int st = 0;
-  if (pri_ok && dua_ok) st = MIOSQP_QP_SOLVED;
-  else if (pinf) { st = MIOSQP_QP_PRIMAL_INFEASIBLE; c->obj_val = QP_INFTY; }
-  else if (dinf) { st = MIOSQP_QP_DUAL_INFEASIBLE; c->obj_val = -QP_INFTY; }
+  c->pri_res = nm.pri;
+  c->dua_res = nm.dua;
+  c->obj_val = obj;
   if (st) {
     c->status = st;
     c->done = 1;
@@ -530,6 +562,387 @@ __global__ __launch_bounds__(1024) void k_obj_sum(Dev d) {
 }
 
 // ------------------------------------------------------------------------------------------
+// batched mode: B independent nodes share the factor (leaves of one wave).  Vectors are
+// [len][Bs] with the batch index fastest, so one wavefront = one matrix row x 64 nodes: the
+// row's entries are wave-uniform (scalar loads, read once for 64 nodes) and every vector access
+// is one coalesced 512-byte line.  No cross-lane reduction is needed at all.
+// ------------------------------------------------------------------------------------------
+#define BSETUP                                                                \
+  const int lane = threadIdx.x & 63;                                          \
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     \
+  const int b = blockIdx.y * 64 + lane;                                       \
+  const size_t Bs = (size_t)d.Bs;
+
+// sum_k val[k] * V[idx[k]][b] over one padded row (wave-uniform row)
+__device__ __forceinline__ double brow_dot(const int *__restrict__ idx, const double *__restrict__ val, int s,
+                                           int e, const double *__restrict__ V, size_t Bs) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = s;
+  for (; k + 4 <= e; k += 4) {
+    a0 = fma(val[k], V[(size_t)idx[k] * Bs], a0);
+    a1 = fma(val[k + 1], V[(size_t)idx[k + 1] * Bs], a1);
+    a2 = fma(val[k + 2], V[(size_t)idx[k + 2] * Bs], a2);
+    a3 = fma(val[k + 3], V[(size_t)idx[k + 3] * Bs], a3);
+  }
+  for (; k < e; k += 2) {
+    a0 = fma(val[k], V[(size_t)idx[k] * Bs], a0);
+    a1 = fma(val[k + 1], V[(size_t)idx[k + 1] * Bs], a1);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ void brow_dot2(const int *__restrict__ idx, const double *__restrict__ val, int s, int e,
+                                          const double *__restrict__ V, const double *__restrict__ W, size_t Bs,
+                                          double &rv, double &rw) {
+  double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+  for (int k = s; k < e; k += 2) {
+    const size_t o0 = (size_t)idx[k] * Bs, o1 = (size_t)idx[k + 1] * Bs;
+    a0 = fma(val[k], V[o0], a0);
+    a1 = fma(val[k + 1], V[o1], a1);
+    c0 = fma(val[k], W[o0], c0);
+    c1 = fma(val[k + 1], W[o1], c1);
+  }
+  rv = a0 + a1;
+  rw = c0 + c1;
+}
+// dense contiguous row segment [j0, j1) against V[j][b]
+__device__ __forceinline__ double bdense_dot(const double *__restrict__ row, int j0, int j1,
+                                             const double *__restrict__ V, size_t Bs) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    a0 = fma(row[j], V[(size_t)j * Bs], a0);
+    a1 = fma(row[j + 1], V[(size_t)(j + 1) * Bs], a1);
+    a2 = fma(row[j + 2], V[(size_t)(j + 2) * Bs], a2);
+    a3 = fma(row[j + 3], V[(size_t)(j + 3) * Bs], a3);
+  }
+  for (; j < j1; j++) a0 = fma(row[j], V[(size_t)j * Bs], a0);
+  return (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(256) void kb_panel_fwd(Dev d) {
+  if (d.ctrl->done) return;
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.n) return;
+  const double acc = brow_dot(d.pv_idx, d.pv_L, d.pv_ptr[row], d.pv_ptr[row + 1], d.b_wh + b, Bs);
+  d.b_cv[row * Bs + b] = d.sigma * d.b_x[row * Bs + b] - d.q[row] - acc;
+}
+
+__global__ __launch_bounds__(256) void kb_tail_fwd(Dev d) {
+  if (d.ctrl->done) return;
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.n) return;
+  const double acc = bdense_dot(d.Linv + (size_t)row * d.ld, 0, row, d.b_cv + b, Bs);
+  d.b_ut[row * Bs + b] = d.d2inv[row] * (d.b_cv[row * Bs + b] + acc);
+}
+
+__global__ __launch_bounds__(256) void kb_tail_bwd(Dev d) {
+  if (d.ctrl->done) return;
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.n) return;
+  const double acc = bdense_dot(d.LinvT + (size_t)row * d.ld, row + 1, d.n, d.b_ut + b, Bs);
+  const double xt = d.b_ut[row * Bs + b] + acc;
+  d.b_xt[row * Bs + b] = xt;
+  if (!d.c_done[b]) {
+    const double xp = d.b_x[row * Bs + b];
+    const double xn = d.alpha * xt + (1.0 - d.alpha) * xp;
+    d.b_x[row * Bs + b] = xn;
+    d.b_dx[row * Bs + b] = xn - xp;
+  }
+}
+
+__global__ __launch_bounds__(256) void kb_panel_bwd(Dev d) {
+  if (d.ctrl->done) return;
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.M) return;
+  const double acc = brow_dot(d.pc_idx, d.pc_L, d.pc_ptr[row], d.pc_ptr[row + 1], d.b_xt + b, Bs);
+  if (d.c_done[b]) return;
+  const size_t o = row * Bs + b;
+  const double rho = d.rho, alpha = d.alpha;
+  const double zp = d.b_z[o], yp = d.b_y[o];
+  const double nu = -rho * d.b_wh[o] - acc;
+  const double zt = zp + (nu - yp) / rho;
+  const double zr = alpha * zt + (1.0 - alpha) * zp;
+  const double v = zr + yp / rho;
+  const double zn = fmin(fmax(v, d.b_l[o]), d.b_u[o]);
+  const double dy = rho * (zr - zn);
+  const double yn = yp + dy;
+  d.b_z[o] = zn;
+  d.b_y[o] = yn;
+  d.b_dy[o] = dy;
+  d.b_wh[o] = zn - yn / rho;
+}
+
+__global__ __launch_bounds__(256) void kb_check_con(Dev d) {
+  if (d.ctrl->done) return;
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.M) return;
+  double ax, adx0;
+  brow_dot2(d.pc_idx, d.pc_A, d.pc_ptr[row], d.pc_ptr[row + 1], d.b_x + b, d.b_dx + b, Bs, ax, adx0);
+  const size_t o = row * Bs + b, MB = (size_t)d.M * Bs;
+  const double ei = d.Einv[row], z = d.b_z[o], l = d.b_l[o], u = d.b_u[o];
+  const bool uinf = u > QP_INFTY * QP_MIN_SCALING, linf = l < -QP_INFTY * QP_MIN_SCALING;
+  double v = d.b_dy[o];
+  if (uinf && linf) v = 0.0;
+  else if (uinf) v = fmin(v, 0.0);
+  else if (linf) v = fmax(v, 0.0);
+  const double adx = ei * adx0;
+  d.b_sm[0 * MB + o] = ei * (ax - z);
+  d.b_sm[1 * MB + o] = ei * ax;
+  d.b_sm[2 * MB + o] = ei * z;
+  d.b_sm[3 * MB + o] = v;
+  d.b_sm[4 * MB + o] = d.E[row] * v;
+  d.b_sm[5 * MB + o] = u * fmax(v, 0.0) + l * fmin(v, 0.0);
+  d.b_sm[6 * MB + o] = uinf ? -1.7e308 : adx;
+  d.b_sm[7 * MB + o] = linf ? 1.7e308 : adx;
+}
+
+// blockIdx.x in [0, nrb): P rows; [nrb, 2 nrb): A^T rows
+__global__ __launch_bounds__(256) void kb_check_var(Dev d) {
+  if (d.ctrl->done) return;
+  BSETUP
+  const int nrb = (d.n + 3) / 4;
+  const bool second = (int)blockIdx.x >= nrb;
+  const int row = ((int)blockIdx.x - (second ? nrb : 0)) * 4 + wv;
+  if (row >= d.n) return;
+  const size_t o = row * Bs + b, NB = (size_t)d.n * Bs;
+  double r0, r1;
+  if (!second) {
+    brow_dot2(d.pb_idx, d.pb_val, d.pb_ptr[row], d.pb_ptr[row + 1], d.b_x + b, d.b_dx + b, Bs, r0, r1);
+    d.b_sn[0 * NB + o] = r0;
+    d.b_sn[1 * NB + o] = d.Dinv[row] * r1;
+  } else {
+    brow_dot2(d.pv_idx, d.pv_At, d.pv_ptr[row], d.pv_ptr[row + 1], d.b_y + b, d.b_sm + 3 * (size_t)d.M * Bs + b, Bs,
+              r0, r1);
+    d.b_sn[2 * NB + o] = r0;
+    d.b_sn[3 * NB + o] = d.Dinv[row] * r1;
+  }
+}
+
+// column-wise reductions: 1024 threads = 64 columns x 16 row groups; fixed order
+#define COLRED(name, OP, init)                                                          \
+  __device__ __forceinline__ double name(double v, double *lds, int bl, int rg) {       \
+    __syncthreads();                                                                    \
+    lds[rg * 64 + bl] = v;                                                              \
+    __syncthreads();                                                                    \
+    double r = lds[bl];                                                                 \
+    for (int w = 1; w < 16; w++) r = OP(r, lds[w * 64 + bl]);                           \
+    return r;                                                                           \
+  }
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+COLRED(colred_max, fmax, 0)
+COLRED(colred_sum, op_add, 0)
+
+__global__ __launch_bounds__(1024) void kb_check_decide(Dev d) {
+  if (d.ctrl->done) return;
+  __shared__ double lds[16 * 64];
+  const int n = d.n, M = d.M, tid = threadIdx.x, bl = tid & 63, rg = tid >> 6;
+  const int b = blockIdx.x * 64 + bl;
+  const size_t Bs = (size_t)d.Bs, MB = (size_t)M * Bs, NB = (size_t)n * Bs;
+  Norms v{0, 0, 0, 0, -1.7e308, 1.7e308, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = rg; j < M; j += 16) {
+    const size_t o = j * Bs + b;
+    v.pri = fmax(v.pri, fabs(d.b_sm[0 * MB + o]));
+    v.nAx = fmax(v.nAx, fabs(d.b_sm[1 * MB + o]));
+    v.nz = fmax(v.nz, fabs(d.b_sm[2 * MB + o]));
+    v.nEv = fmax(v.nEv, fabs(d.b_sm[4 * MB + o]));
+    v.lhs += d.b_sm[5 * MB + o];
+    v.amax_u = fmax(v.amax_u, d.b_sm[6 * MB + o]);
+    v.amin_l = fmin(v.amin_l, d.b_sm[7 * MB + o]);
+  }
+  for (int i = rg; i < n; i += 16) {
+    const size_t o = i * Bs + b;
+    const double di = d.Dinv[i], px = d.b_sn[0 * NB + o], aty = d.b_sn[2 * NB + o], q = d.q[i], x = d.b_x[o],
+                 dx = d.b_dx[o];
+    v.dua = fmax(v.dua, fabs(di * (px + q + aty)));
+    v.nPx = fmax(v.nPx, fabs(di * px));
+    v.nAty = fmax(v.nAty, fabs(di * aty));
+    v.nq = fmax(v.nq, fabs(di * q));
+    v.nPdx = fmax(v.nPdx, fabs(d.b_sn[1 * NB + o]));
+    v.nAtv = fmax(v.nAtv, fabs(d.b_sn[3 * NB + o]));
+    v.ndx = fmax(v.ndx, fabs(d.D[i] * dx));
+    v.qdx += q * dx;
+    v.xPx += x * px;
+    v.qx += q * x;
+  }
+  v.pri = colred_max(v.pri, lds, bl, rg);
+  v.nAx = colred_max(v.nAx, lds, bl, rg);
+  v.nz = colred_max(v.nz, lds, bl, rg);
+  v.nEv = colred_max(v.nEv, lds, bl, rg);
+  v.lhs = colred_sum(v.lhs, lds, bl, rg);
+  v.amax_u = colred_max(v.amax_u, lds, bl, rg);
+  v.amin_l = -colred_max(-v.amin_l, lds, bl, rg);
+  v.dua = colred_max(v.dua, lds, bl, rg) * d.cinv;
+  v.nPx = colred_max(v.nPx, lds, bl, rg);
+  v.nAty = colred_max(v.nAty, lds, bl, rg);
+  v.nq = colred_max(v.nq, lds, bl, rg);
+  v.nPdx = colred_max(v.nPdx, lds, bl, rg);
+  v.nAtv = colred_max(v.nAtv, lds, bl, rg);
+  v.ndx = colred_max(v.ndx, lds, bl, rg);
+  v.qdx = colred_sum(v.qdx, lds, bl, rg);
+  v.xPx = colred_sum(v.xPx, lds, bl, rg);
+  v.qx = colred_sum(v.qx, lds, bl, rg);
+  if (rg != 0) return;  // wave 0 decides for its 64 columns
+  Ctrl *c = d.ctrl;
+  bool newly = false;
+  if (!d.c_done[b]) {
+    double obj;
+    const int st = decide_status(d, v, obj);
+    d.c_pri[b] = v.pri;
+    d.c_dua[b] = v.dua;
+    d.c_obj[b] = obj;
+    if (st) {
+      d.c_status[b] = st;
+      d.c_iter[b] = c->iter;  // kb_tick already counted this chunk
+      d.c_done[b] = 1;
+      newly = true;
+    }
+  }
+  const int cnt = __popcll(__ballot(newly));
+  if (bl == 0 && cnt > 0) {
+    const int before = atomicAdd(&c->ndone, cnt);
+    if (before + cnt >= c->B) c->done = 1;
+  }
+}
+
+// first kernel of a batched chunk: counts the chunk's iterations unless everything is decided
+__global__ void kb_tick(Dev d, int iters_in_chunk) {
+  if (!d.ctrl->done) d.ctrl->iter += iters_in_chunk;
+}
+
+__global__ void kb_reset(Dev d, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < d.Bs) {
+    d.c_done[b] = b >= B;
+    d.c_status[b] = MIOSQP_QP_UNSOLVED;
+    d.c_iter[b] = 0;
+    d.c_pri[b] = d.c_dua[b] = d.c_obj[b] = 0.0;
+    d.c_lower[b] = __builtin_nan("");
+  }
+  if (b == 0) {
+    Ctrl *c = d.ctrl;
+    c->done = 0;
+    c->status = MIOSQP_QP_UNSOLVED;
+    c->iter = 0;
+    c->pad = 0;
+    c->B = B;
+    c->ndone = 0;
+  }
+}
+
+// node-major staging -> scaled, batch-fastest working vectors (block = 64 columns x 4 rows)
+__global__ __launch_bounds__(256) void kb_prepare(Dev d, int B) {
+  const int lane = threadIdx.x & 63, b = blockIdx.y * 64 + lane;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t Bs = (size_t)d.Bs, n = d.n, M = d.M;
+  const bool act = b < B;
+  const double *rl = d.b_raw, *ru = rl + (size_t)B * M, *rx = ru + (size_t)B * M, *ry = rx + (size_t)B * n;
+  if (j < d.M) {
+    const size_t o = j * Bs + b;
+    d.b_l[o] = act ? d.E[j] * fmax(rl[(size_t)b * M + j], -QP_INFTY) : 0.0;
+    d.b_u[o] = act ? d.E[j] * fmin(ru[(size_t)b * M + j], QP_INFTY) : 0.0;
+    d.b_y[o] = act ? d.c * d.Einv[j] * ry[(size_t)b * M + j] : 0.0;
+    d.b_dy[o] = 0.0;
+  }
+  if (j < d.n) {
+    const size_t o = j * Bs + b;
+    d.b_x[o] = act ? d.Dinv[j] * rx[(size_t)b * n + j] : 0.0;
+    d.b_dx[o] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void kb_warm_z(Dev d) {
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.M) return;
+  const double z = brow_dot(d.pc_idx, d.pc_A, d.pc_ptr[row], d.pc_ptr[row + 1], d.b_x + b, Bs);
+  const size_t o = row * Bs + b;
+  d.b_z[o] = z;
+  d.b_wh[o] = z - d.b_y[o] / d.rho;
+}
+
+// unscale (or build the certificate) per column, then the integer clamp of node.py:131-136
+__global__ __launch_bounds__(1024) void kb_finish(Dev d, int B) {
+  __shared__ double lds[16 * 64];
+  const int n = d.n, M = d.M, tid = threadIdx.x, bl = tid & 63, rg = tid >> 6;
+  const int b = blockIdx.x * 64 + bl;
+  const size_t Bs = (size_t)d.Bs;
+  int st = d.c_status[b];
+  if (st == MIOSQP_QP_UNSOLVED) st = MIOSQP_QP_MAX_ITER_REACHED;
+  double ndy = 0, ndx = 0;
+  for (int j = rg; j < M; j += 16) ndy = fmax(ndy, fabs(d.E[j] * d.b_dy[j * Bs + b]));
+  for (int i = rg; i < n; i += 16) ndx = fmax(ndx, fabs(d.D[i] * d.b_dx[i * Bs + b]));
+  ndy = colred_max(ndy, lds, bl, rg);
+  ndx = colred_max(ndx, lds, bl, rg);
+  const double nan = __builtin_nan("");
+  for (int i = rg; i < n; i += 16) {
+    const size_t o = i * Bs + b;
+    double v;
+    if (st == MIOSQP_QP_PRIMAL_INFEASIBLE) v = nan;
+    else if (st == MIOSQP_QP_DUAL_INFEASIBLE) v = d.D[i] * d.b_dx[o] / ndx;
+    else v = d.D[i] * d.b_x[o];
+    d.b_xfin[o] = v;
+  }
+  for (int j = rg; j < M; j += 16) {
+    const size_t o = j * Bs + b;
+    double v;
+    if (st == MIOSQP_QP_PRIMAL_INFEASIBLE) v = d.E[j] * d.b_dy[o] / ndy;
+    else if (st == MIOSQP_QP_DUAL_INFEASIBLE) v = nan;
+    else v = d.cinv * d.E[j] * d.b_y[o];
+    d.b_yfin[o] = v;
+  }
+  __syncthreads();
+  if (b < B && (st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED)) {
+    const double *rl = d.b_raw, *ru = rl + (size_t)B * M;
+    for (int k = rg; k < d.n_int; k += 16) {
+      const size_t o = (size_t)d.i_idx[k] * Bs + b;
+      const double lo = rl[(size_t)b * M + d.m_orig + k], hi = ru[(size_t)b * M + d.m_orig + k];
+      d.b_xfin[o] = fmin(fmax(d.b_xfin[o], lo), hi);
+    }
+  }
+  if (rg == 0 && d.c_status[b] == MIOSQP_QP_UNSOLVED) {
+    d.c_status[b] = MIOSQP_QP_MAX_ITER_REACHED;
+    d.c_iter[b] = d.ctrl->iter;
+  }
+}
+
+__global__ __launch_bounds__(256) void kb_obj_rows(Dev d) {
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.n) return;
+  const double acc = brow_dot(d.pr_idx, d.pr_val, d.pr_ptr[row], d.pr_ptr[row + 1], d.b_xfin + b, Bs);
+  d.b_sn[row * Bs + b] = d.b_xfin[row * Bs + b] * (0.5 * acc + d.qraw[row]);
+}
+
+__global__ __launch_bounds__(1024) void kb_obj_sum(Dev d) {
+  __shared__ double lds[16 * 64];
+  const int tid = threadIdx.x, bl = tid & 63, rg = tid >> 6, b = blockIdx.x * 64 + bl;
+  const size_t Bs = (size_t)d.Bs;
+  double s = 0;
+  for (int i = rg; i < d.n; i += 16) s += d.b_sn[i * Bs + b];
+  s = colred_sum(s, lds, bl, rg);
+  if (rg == 0) {
+    const int st = d.c_status[b];
+    d.c_lower[b] = (st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED) ? s : __builtin_nan("");
+  }
+}
+
+// batch-fastest answers -> node-major staging out
+__global__ __launch_bounds__(256) void kb_export(Dev d, int B) {
+  const int lane = threadIdx.x & 63, b = blockIdx.y * 64 + lane;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const size_t Bs = (size_t)d.Bs, n = d.n, M = d.M;
+  double *ox = d.b_out, *oy = ox + (size_t)B * n;
+  if (j < d.n) ox[(size_t)b * n + j] = d.b_xfin[j * Bs + b];
+  if (j < d.M) oy[(size_t)b * M + j] = d.b_yfin[j * Bs + b];
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 inline int pick_tpr(double avg_row) {
@@ -582,6 +995,15 @@ struct miosqp_qp_engine {
   double *d_in = nullptr;
   bool have_int = false;
   int64_t nnzA = 0, nnzPtriu = 0;
+  // batched mode
+  int Bcap = 0;  // capacity (columns), multiple of 64; 0 = batched mode not allocated
+  double *hb_in = nullptr, *hb_out = nullptr;
+  int *hb_int = nullptr;       // status | iter
+  double *hb_dbl = nullptr;    // pri | dua | obj | lower
+  hipGraphExec_t xb_full[16] = {}, xb_tail[16] = {};
+  hipGraph_t gb_full[16] = {}, gb_tail[16] = {};
+  double bloop_ms = 0.0;
+  int64_t bloop_iters = 0, bloop_node_iters = 0;
 };
 
 namespace {
@@ -617,7 +1039,7 @@ void launch_check(miosqp_qp_engine *e, int iters_in_chunk) {
   // P rows and A^T rows in one launch; both use 64 threads per row
   const int nblk = 2 * ((d.n + 3) / 4);
   hipLaunchKernelGGL((k_check_var<64, 64>), dim3(nblk), dim3(256), 0, e->stream, d);
-  hipLaunchKernelGGL(k_check_decide, dim3(1), dim3(1024), 0, e->stream, d, iters_in_chunk);
+  hipLaunchKernelGGL(k_check_decide, dim3(1), dim3(256), 0, e->stream, d, iters_in_chunk);
 }
 
 int capture_chunk(miosqp_qp_engine *e, int iters, hipGraph_t *g, hipGraphExec_t *x) {
@@ -679,6 +1101,128 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
   return 0;
 }
 
+
+// ---- batched mode (host) -------------------------------------------------------------------
+void launch_iteration_b(miosqp_qp_engine *e, int ntiles) {
+  const Dev &d = e->d;
+  hipLaunchKernelGGL(kb_panel_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_tail_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_tail_bwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_panel_bwd, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+}
+
+int capture_chunk_b(miosqp_qp_engine *e, int iters, int ntiles, hipGraph_t *g, hipGraphExec_t *x) {
+  const Dev &d = e->d;
+  HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+  hipLaunchKernelGGL(kb_tick, dim3(1), dim3(1), 0, e->stream, d, iters);
+  for (int i = 0; i < iters; i++) launch_iteration_b(e, ntiles);
+  hipLaunchKernelGGL(kb_check_con, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_check_var, dim3(2 * ((d.n + 3) / 4), ntiles), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_check_decide, dim3(ntiles), dim3(1024), 0, e->stream, d);
+  HIPCHK(hipStreamEndCapture(e->stream, g));
+  HIPCHK(hipGraphInstantiate(x, *g, nullptr, nullptr, 0));
+  return 0;
+}
+
+int alloc_batch(miosqp_qp_engine *e, int cap) {
+  Dev &d = e->d;
+  const size_t n = e->n, M = e->M;
+  const size_t Bs = ((size_t)cap + 63) & ~(size_t)63;
+  d.Bs = (int)Bs;
+#define ALB(field, count)                            \
+  do {                                               \
+    int rc__ = dalloc(e, &d.field, (size_t)(count)); \
+    if (rc__) return rc__;                           \
+  } while (0)
+  ALB(b_l, M * Bs); ALB(b_u, M * Bs); ALB(b_x, n * Bs); ALB(b_z, M * Bs); ALB(b_y, M * Bs); ALB(b_wh, M * Bs);
+  ALB(b_cv, n * Bs); ALB(b_ut, n * Bs); ALB(b_xt, n * Bs); ALB(b_dx, n * Bs); ALB(b_dy, M * Bs);
+  ALB(b_sm, 8 * M * Bs); ALB(b_sn, 4 * n * Bs); ALB(b_xfin, n * Bs); ALB(b_yfin, M * Bs);
+  ALB(b_raw, Bs * (3 * M + n)); ALB(b_out, Bs * (n + M));
+  ALB(c_done, Bs); ALB(c_status, Bs); ALB(c_iter, Bs); ALB(c_pri, Bs); ALB(c_dua, Bs); ALB(c_obj, Bs);
+  ALB(c_lower, Bs);
+#undef ALB
+  HIPCHK(hipHostMalloc((void **)&e->hb_in, sizeof(double) * Bs * (3 * M + n), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&e->hb_out, sizeof(double) * Bs * (n + M), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&e->hb_int, sizeof(int) * 2 * Bs, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&e->hb_dbl, sizeof(double) * 4 * Bs, hipHostMallocDefault));
+  e->Bcap = (int)Bs;
+  return 0;
+}
+
+// one slice of at most Bcap nodes
+int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, const double *x0, const double *y0,
+                double *x_out, double *y_out, miosqp_qp_info *info) {
+  const Dev &d = e->d;
+  const size_t n = e->n, M = e->M;
+  const double t0 = wall();
+  const int ntiles = (B + 63) / 64;
+  if (ntiles > 16) { g_err = "solve_batch: more than 1024 columns per slice"; return MIOSQP_EARG; }
+  if (!e->xb_full[ntiles - 1]) {
+    int rc = capture_chunk_b(e, e->chunk, ntiles, &e->gb_full[ntiles - 1], &e->xb_full[ntiles - 1]);
+    if (!rc && e->tail_iters > 0)
+      rc = capture_chunk_b(e, e->tail_iters, ntiles, &e->gb_tail[ntiles - 1], &e->xb_tail[ntiles - 1]);
+    if (rc) return rc;
+  }
+  double *h = e->hb_in;
+  memcpy(h, l, sizeof(double) * B * M);
+  memcpy(h + B * M, u, sizeof(double) * B * M);
+  memcpy(h + 2 * B * M, x0, sizeof(double) * B * n);
+  memcpy(h + 2 * B * M + B * n, y0, sizeof(double) * B * M);
+  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  HIPCHK(hipMemcpyAsync(d.b_raw, h, sizeof(double) * B * (3 * M + n), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(kb_reset, dim3((d.Bs + 255) / 256), dim3(256), 0, e->stream, d, B);
+  const int big = (int)(n > M ? n : M);
+  hipLaunchKernelGGL(kb_prepare, dim3((big + 3) / 4, ntiles), dim3(256), 0, e->stream, d, B);
+  hipLaunchKernelGGL(kb_warm_z, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+  const int nfull = e->st.max_iter / e->chunk;
+  bool done = false;
+  int decided = 0;
+  for (int k = 0; k < nfull && !done; k++) {
+    HIPCHK(hipEventRecord(e->evc0, e->stream));
+    HIPCHK(hipGraphLaunch(e->xb_full[ntiles - 1], e->stream));
+    HIPCHK(hipEventRecord(e->evc1, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e->evc0, e->evc1));
+    e->bloop_ms += ms;
+    e->bloop_iters += e->chunk;
+    e->bloop_node_iters += (int64_t)e->chunk * (B - decided);  // columns still iterating in this chunk
+    decided = e->h_ctrl->ndone;
+    done = e->h_ctrl->done != 0;
+  }
+  if (!done && e->tail_iters > 0) HIPCHK(hipGraphLaunch(e->xb_tail[ntiles - 1], e->stream));
+  hipLaunchKernelGGL(kb_finish, dim3(ntiles), dim3(1024), 0, e->stream, d, B);
+  hipLaunchKernelGGL(kb_obj_rows, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_obj_sum, dim3(ntiles), dim3(1024), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_export, dim3((big + 3) / 4, ntiles), dim3(256), 0, e->stream, d, B);
+  HIPCHK(hipMemcpyAsync(e->hb_out, d.b_out, sizeof(double) * B * (n + M), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_int, d.c_status, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_int + B, d.c_iter, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_dbl, d.c_pri, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_dbl + B, d.c_dua, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_dbl + 2 * B, d.c_obj, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_dbl + 3 * B, d.c_lower, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  memcpy(x_out, e->hb_out, sizeof(double) * B * n);
+  memcpy(y_out, e->hb_out + B * n, sizeof(double) * B * M);
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  const double wall_s = wall() - t0;
+  for (int b = 0; b < B; b++) {
+    info[b].status_val = e->hb_int[b];
+    info[b].iter = e->hb_int[B + b];
+    info[b].pri_res = e->hb_dbl[b];
+    info[b].dua_res = e->hb_dbl[B + b];
+    info[b].obj_val = e->hb_dbl[2 * B + b];
+    info[b].lower = e->hb_dbl[3 * B + b];
+    info[b].run_time = wall_s / B;  // the wave's wall time, shared equally
+    info[b].device_time = 1e-3 * ms / B;
+  }
+  return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -728,6 +1272,16 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->h_in) hipHostFree(e->h_in);
   if (e->h_out) hipHostFree(e->h_out);
   if (e->h_ctrl) hipHostFree(e->h_ctrl);
+  if (e->hb_in) hipHostFree(e->hb_in);
+  if (e->hb_out) hipHostFree(e->hb_out);
+  if (e->hb_int) hipHostFree(e->hb_int);
+  if (e->hb_dbl) hipHostFree(e->hb_dbl);
+  for (int k = 0; k < 16; k++) {
+    if (e->xb_full[k]) hipGraphExecDestroy(e->xb_full[k]);
+    if (e->xb_tail[k]) hipGraphExecDestroy(e->xb_tail[k]);
+    if (e->gb_full[k]) hipGraphDestroy(e->gb_full[k]);
+    if (e->gb_tail[k]) hipGraphDestroy(e->gb_tail[k]);
+  }
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->evc0) hipEventDestroy(e->evc0);
@@ -944,11 +1498,24 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, 
 
 int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const double *u, const double *x0,
                           const double *y0, double *x_out, double *y_out, miosqp_qp_info *info) {
-  if (!e || B < 0) return MIOSQP_EARG;
+  if (!e || B < 0 || (B > 0 && (!l || !u || !x0 || !y0 || !x_out || !y_out || !info))) return MIOSQP_EARG;
+  if (!e->have_int) {
+    g_err = "solve_batch: call miosqp_qp_set_integer_rows first";
+    return MIOSQP_EARG;
+  }
   const size_t n = e->n, M = e->M;
-  for (int b = 0; b < B; b++) {
-    int rc = miosqp_qp_solve_node(e, l + b * M, u + b * M, x0 + b * n, y0 + b * M, x_out + b * n, y_out + b * M,
-                                  info + b);
+  for (size_t k = 0; k < (size_t)B * M; k++)
+    if (l[k] > u[k]) return MIOSQP_EBOUNDS;
+  if (e->Bcap == 0) {
+    int cap = e->st.max_batch > 1 ? e->st.max_batch : 64;
+    if (cap > 1024) cap = 1024;
+    int rc = alloc_batch(e, cap);
+    if (rc) return rc;
+  }
+  for (int s0 = 0; s0 < B; s0 += e->Bcap) {
+    const int nb = B - s0 < e->Bcap ? B - s0 : e->Bcap;
+    int rc = solve_slice(e, nb, l + s0 * M, u + s0 * M, x0 + s0 * n, y0 + s0 * M, x_out + s0 * n, y_out + s0 * M,
+                         info + s0);
     if (rc) return rc;
   }
   return 0;
@@ -1010,12 +1577,36 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
   return 0;
 }
 
+int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters, int64_t *node_iters,
+                              int32_t reset) {
+  if (!e) return MIOSQP_EARG;
+  if (ms) *ms = e->bloop_ms;
+  if (batch_iters) *batch_iters = e->bloop_iters;
+  if (node_iters) *node_iters = e->bloop_node_iters;
+  if (reset) {
+    e->bloop_ms = 0.0;
+    e->bloop_iters = e->bloop_node_iters = 0;
+  }
+  return 0;
+}
+
 int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, double *usec, double *bytes) {
-  if (!e || which < 0 || which > 4 || reps <= 0 || !usec) return MIOSQP_EARG;
+  if (!e || which < 0 || (which > 4 && which < 10) || which > 14 || reps <= 0 || !usec) return MIOSQP_EARG;
+  if (which >= 10 && e->Bcap == 0) {
+    g_err = "time_kernel: batched kernels need a prior solve_batch";
+    return MIOSQP_EARG;
+  }
   const Dev &d = e->d;
+  const int ntiles = e->Bcap / 64;
+  if (which >= 10) hipLaunchKernelGGL(kb_reset, dim3((d.Bs + 255) / 256), dim3(256), 0, e->stream, d, e->Bcap);
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, d);
   auto one = [&]() {
     switch (which) {
+      case 10: hipLaunchKernelGGL(kb_panel_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
+      case 11: hipLaunchKernelGGL(kb_tail_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
+      case 12: hipLaunchKernelGGL(kb_tail_bwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
+      case 13: hipLaunchKernelGGL(kb_panel_bwd, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
+      case 14: launch_iteration_b(e, ntiles); break;
       case 0: DISPATCH_TPR(e->tpr_pv, k_panel_fwd, d.n, e->stream, d); break;
       case 1: DISPATCH_TPR(e->tpr_tail, k_tail_fwd, d.n, e->stream, d); break;
       case 2: DISPATCH_TPR(e->tpr_tail, k_tail_bwd, d.n, e->stream, d); break;
@@ -1034,7 +1625,16 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
   if (bytes) {
     double b[5];
     kernel_bytes(e, b);
-    *bytes = b[which];
+    if (which < 10) {
+      *bytes = b[which];
+    } else {
+      // batched: matrix terms once per launch, per-node vector terms times the columns
+      const double n = e->n, M = e->M, np = (double)e->fa.nnz_panel, nt = (double)e->fa.nnz_tail, B = e->Bcap;
+      const double mat[5] = {np * 12 + (n + 1) * 4, nt * 12 + (n + 1) * 4, nt * 12 + (n + 1) * 4,
+                             np * 12 + (M + 1) * 4, 2 * (np + nt) * 12 + 2 * (n + M + 1) * 4 + (n + M) * 12};
+      const double vec[5] = {(M + 3 * n) * 8, 3 * n * 8, 5 * n * 8, (n + 10 * M) * 8, (6 * n + 16 * M) * 8};
+      *bytes = mat[which - 10] + B * vec[which - 10];
+    }
   }
   return 0;
 }

@@ -114,6 +114,23 @@ class ShardedSearch(object):
             self._visit(rule)
         self.sync_incumbent()
 
+    def step_batched(self, width):
+        """One wave as ONE batched relaxation call: take up to `width` local leaves in the order the
+        exploration rule would visit them, solve them together, then bound/branch each in that order."""
+        w = self.work
+        rule = w.settings['tree_explor_rule']
+        wave = []
+        while w.leaves and len(wave) < width:
+            wave.append(w.choose_leaf(rule))
+        if wave:
+            w.solve_wave(wave)
+            for leaf in wave:
+                w.bound_and_branch(leaf)
+                w.iter_num += 1
+                self.nodes += 1
+                self.iters += leaf.num_iter
+        self.sync_incumbent()
+
     def sync_incumbent(self):
         w = self.work
         if self.comm.world == 1:

@@ -198,6 +198,12 @@ class OSQP(object):
                "get_loop_stats")
         return ms.value, it.value
 
+    def batch_stats(self, reset=False):
+        ms, bi, ni = C.c_double(), C.c_int64(), C.c_int64()
+        _check(self._lib.miosqp_qp_get_batch_stats(self._h, C.byref(ms), C.byref(bi), C.byref(ni), int(reset)),
+               "get_batch_stats")
+        return ms.value, bi.value, ni.value
+
     def time_kernel(self, which, reps=200):
         us, by = C.c_double(), C.c_double()
         _check(self._lib.miosqp_qp_time_kernel(self._h, which, reps, C.byref(us), C.byref(by)),

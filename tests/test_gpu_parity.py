@@ -227,3 +227,78 @@ def test_config2_full_size_root_and_children(oracle_mod):
         ro2 = o.solve()
         assert (r2.status_val, r2.iter) == (ro2.info.status_val, ro2.info.iter)
         assert rel(r2.y, ro2.y) <= SOL_TOL
+
+
+def _wave_of_nodes(oracle_mod, pr, count):
+    """A realistic wave: nodes produced by actually branching (oracle-backed host search)."""
+    from miosqp_amd import bnb, dist
+    st = dict(problems.BNB_SETTINGS)
+    st["tree_explor_rule"] = 0
+    model = bnb.MIOSQP(backend=oracle_mod)
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
+                dict(problems.QP_SETTINGS))
+    s = dist.ShardedSearch(model)
+    s.expand_until(count)
+    return model.work.leaves[:count]
+
+
+@pytest.mark.parametrize("n,m,p,seed,count", [(20, 40, 10, 1, 7), (50, 100, 25, 2, 70), (130, 260, 65, 3, 130)])
+def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count):
+    """solve_batch on a wave of real B&B leaves == solve_node on each == the oracle."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    leaves = _wave_of_nodes(oracle_mod, pr, count)
+    assert len(leaves) >= 2
+    A, l, u = problems.extended(pr)
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, max_batch=64, **problems.QP_SETTINGS)  # 64 < count: slices
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    g.set_integer_rows(pr["i_idx"], m)
+    L = np.stack([lf.l for lf in leaves]); U = np.stack([lf.u for lf in leaves])
+    X = np.stack([lf.x for lf in leaves]); Y = np.stack([lf.y for lf in leaves])
+    rb = g.solve_batch(L, U, X, Y)
+    k_int = len(pr["i_idx"])
+    for k in range(len(leaves)):
+        r1 = g.solve_node(L[k], U[k], X[k], Y[k])
+        assert rb.status_val[k] == r1.status_val and rb.iter[k] == r1.iter, k
+        o.update(l=L[k], u=U[k])
+        o.warm_start(x=X[k], y=Y[k])
+        ro = o.solve()
+        assert (rb.status_val[k], rb.iter[k]) == (ro.info.status_val, ro.info.iter), k
+        if ro.info.status_val in (1, -2):
+            assert rel(rb.x[k], r1.x) <= SOL_TOL and rel(rb.y[k], r1.y) <= SOL_TOL
+            xo = ro.x.copy()
+            ii = pr["i_idx"]
+            xo[ii] = np.minimum(np.maximum(xo[ii], L[k][-k_int:]), U[k][-k_int:])
+            assert rel(rb.x[k], xo) <= SOL_TOL and rel(rb.y[k], ro.y) <= SOL_TOL
+            lo = 0.5 * xo.dot(pr["P"].dot(xo)) + pr["q"].dot(xo)
+            assert abs(rb.lower[k] - lo) <= 1e-9 * max(1.0, abs(lo))
+            assert abs(rb.lower[k] - r1.lower) <= 1e-9 * max(1.0, abs(lo))
+        else:
+            assert np.isnan(rb.lower[k])
+    # a second identical call is bit-identical
+    rb2 = g.solve_batch(L, U, X, Y)
+    np.testing.assert_array_equal(rb.x, rb2.x)
+    np.testing.assert_array_equal(rb.iter, rb2.iter)
+
+
+def test_batched_search_finds_the_same_optimum():
+    """Waves of 8 leaves through solve_batch reach the sequential search's optimum."""
+    from miosqp_amd import bnb, dist
+    pr = problems.random_miqp(30, 150, 15, seed=4)
+    out = []
+    for width in (1, 8):
+        model = bnb.MIOSQP()
+        qs = dict(problems.QP_SETTINGS, max_batch=64)
+        model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                    dict(problems.BNB_SETTINGS), qs)
+        s = dist.ShardedSearch(model)
+        while model.work.leaves:
+            s.step_batched(width)
+        model.work.get_return_status()
+        model.work.get_return_solution()
+        out.append((model.work.status, model.work.upper_glob, model.work.x.copy(), s.nodes))
+    assert out[0][0] == out[1][0] == bnb.MI_SOLVED
+    assert abs(out[0][1] - out[1][1]) <= 1e-3 * max(1.0, abs(out[0][1]))
+    ii = pr["i_idx"]
+    np.testing.assert_array_equal(out[0][2][ii], out[1][2][ii])
