@@ -7,7 +7,9 @@ Workload (BASELINE.json configs[1]): the random MIQP of the reference's own gene
 (/root/reference/examples/random_miqp/run_example.py:71-83, seed 0, density 0.7) at n=500,
 m=1000, 250 binaries, explored by the branch-and-bound host logic one node at a time per GPU with
 the reference's settings (run_example.py:98-116).  One "step" = one wave = `--wave` node
-relaxations per rank (default 1: node-at-a-time) followed by the incumbent exchange.  Inputs
+relaxations per rank (default 1: node-at-a-time) followed by the incumbent exchange.  When a tree
+closes (seed 0 closes after ~220 nodes) the search re-roots on the next MIQP of a stream that shares
+P and A -- hence the factor -- and draws new q, l, u, through MIOSQP.update_vectors.  Inputs
 (factor, matrices) are resident in HBM before the timed region; the per-node vectors (l, u, x0,
 y0: 34 KB) are part of the path and travel inside it.  N > 1 shards the open leaves over the
 ranks (miosqp_amd/dist.py), one process per GPU, RCCL only for the incumbent: weak scaling.
@@ -62,7 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-width", type=int, default=256,
                     help="extra leg: leaves per batched wave (BASELINE configs[2]); 0 = skip")
-    ap.add_argument("--batch-waves", type=int, default=3)
+    ap.add_argument("--batch-waves", type=int, default=12)
     args = ap.parse_args()
 
     import torch
@@ -98,23 +100,37 @@ def main():
     t_setup = time.time() - t_setup
     eng = model.work.solver
     srch = dist.ShardedSearch(model, comm)
-    # identical on every rank: open enough leaves to deal at least one to each rank
-    srch.expand_until(max(2 * world, 2))
-    if world > 1:
-        srch.deal()
+    m_orig = cfg["m"]
+    rng = np.random.RandomState(args.seed + 12345)
+    stream = dict(instances=1)
+
+    def next_instance():
+        """The tree closed: re-root on the next MIQP of the stream.  Same P and A, hence the same
+        factor in HBM; new q, l, u drawn like the generator draws them (run_example.py:76-80), pushed
+        through MIOSQP.update_vectors exactly like the reference's MPC loop does
+        (/root/reference/miosqp/solver.py:174-205).  Every rank draws the same numbers."""
+        q = rng.randn(cfg["n"])
+        u = 2 + rng.rand(m_orig)
+        l = -2 + rng.rand(m_orig)
+        model.update_vectors(q=q, l=l, u=u)
+        srch.begin_instance()
+        stream["instances"] += 1
 
     def sync():
         comm.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        srch.step(args.wave)
+    def run_steps(count, width, batched):
+        for _ in range(count):
+            if srch.step(width, batched) == 0:
+                next_instance()
+
+    run_steps(args.warmup, args.wave, False)
     sync()
     eng.loop_stats(reset=True)
-    n0, i0 = srch.nodes, srch.iters
+    n0, i0, inst0 = srch.nodes, srch.iters, stream["instances"]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        srch.step(args.wave)
+    run_steps(args.steps, args.wave, False)
     sync()
     dt = time.perf_counter() - t0
     loop_ms, loop_iters = eng.loop_stats()
@@ -126,19 +142,19 @@ def main():
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt_max = float(tmax.item())
     iters, nodes = float(tot[0]), float(tot[1])
+    instances = stream["instances"] - inst0 + 1
 
-    # ---- extra leg (BASELINE configs[2]): the same tree, waves of `batch_width` leaves per rank in
-    #      ONE batched device call each (not part of `value`) --------------------------------------
+    # ---- extra leg (BASELINE configs[2]): the same stream explored in waves of up to `batch_width`
+    #      leaves per rank, each wave ONE batched device call (not part of `value`) -------------------
     batched = None
     if args.batch_width > 0:
-        srch.expand_until(args.batch_width)
-        srch.step_batched(args.batch_width)  # warm-up wave: graph capture, allocation
+        next_instance()
+        run_steps(12, args.batch_width, True)  # warm-up: graph capture, allocation, frontier ramp-up
         sync()
         eng.batch_stats(reset=True)
         n1, i1 = srch.nodes, srch.iters
         t1 = time.perf_counter()
-        for _ in range(args.batch_waves):
-            srch.step_batched(args.batch_width)
+        run_steps(args.batch_waves, args.batch_width, True)
         sync()
         dtb = time.perf_counter() - t1
         bms, bit, bnode = eng.batch_stats()
@@ -147,7 +163,8 @@ def main():
             tb = torch.tensor([dtb], dtype=torch.float64, device=dev)
             td.all_reduce(tb, op=td.ReduceOp.MAX)
             dtb = float(tb.item())
-        batched = dict(wave=args.batch_width, waves=args.batch_waves, nodes=float(totb[1]),
+        batched = dict(max_wave=args.batch_width, waves=args.batch_waves, nodes=float(totb[1]),
+                       mean_wave=round(float(totb[1]) / max(1, args.batch_waves * world), 1),
                        node_iters_per_s=round(float(totb[0]) / dtb, 1), nodes_per_s=round(float(totb[1]) / dtb, 2),
                        lockstep_iters=bit, device_us_per_lockstep_iter=round(1e3 * bms / max(1, bit), 2),
                        device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
@@ -182,7 +199,8 @@ def main():
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
                                qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3)),
                    roofline=roof)
-        if batched is not None:
+        out["config"]["instances_in_timed_region"] = instances
+        if batched is not None and batched["lockstep_iters"] > 0:
             bk = []
             for k in range(4):
                 us, by = eng.time_kernel(10 + k, 30)

@@ -24,6 +24,9 @@ class LocalComm(object):
     def incumbent(self, value, x):
         return value, 0, x
 
+    def exchange(self, value, x, nleaves):
+        return value, 0, x, nleaves
+
     def sum(self, arr):
         return np.asarray(arr, dtype=np.float64)
 
@@ -40,21 +43,31 @@ class TorchComm(object):
         self.torch, self.dist, self.device = torch, dist, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def incumbent(self, value, x):
-        """(best value over ranks, owner rank, owner's x).  Ties go to the lowest rank."""
+    def exchange(self, value, x, nleaves, have=None):
+        """One all-gather of (incumbent value, open-leaf count) per rank, then -- only when some
+        rank holds a better incumbent than `have` -- a broadcast of the owner's x.
+        Returns (best value, owner rank, owner's x or None, total open leaves).  Ties go to the
+        lowest rank, so every rank takes the same decision."""
         t = self.torch
-        mine = t.tensor([value], dtype=t.float64, device=self.device)
-        allv = t.empty(self.world, dtype=t.float64, device=self.device)
+        mine = t.tensor([value, float(nleaves)], dtype=t.float64, device=self.device)
+        allv = t.empty(2 * self.world, dtype=t.float64, device=self.device)
         self.dist.all_gather_into_tensor(allv, mine)
-        vals = allv.cpu().numpy()
-        owner = int(np.argmin(vals))
-        best = float(vals[owner])
-        if not np.isfinite(best):
-            return best, owner, x
+        tab = allv.cpu().numpy().reshape(self.world, 2)
+        owner = int(np.argmin(tab[:, 0]))
+        best = float(tab[owner, 0])
+        total = int(round(tab[:, 1].sum()))
+        # every rank holds the same previous global incumbent, so this test is rank-uniform
+        prev = float(np.max(tab[:, 0])) if have is None else have
+        if not np.isfinite(best) or not best < prev:
+            return best, owner, None, total
         buf = t.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self.device) \
             if self.rank == owner else t.empty(len(x), dtype=t.float64, device=self.device)
         self.dist.broadcast(buf, src=owner)
-        return best, owner, buf.cpu().numpy()
+        return best, owner, buf.cpu().numpy(), total
+
+    def incumbent(self, value, x):
+        best, owner, xb, _ = self.exchange(value, x, 0)
+        return best, owner, (x if xb is None else xb)
 
     def sum(self, arr):
         t = self.torch
@@ -67,7 +80,12 @@ class TorchComm(object):
 
 
 class ShardedSearch(object):
-    """Drives one rank's share of the tree of an already set-up MIOSQP model."""
+    """Drives one rank's share of the tree of an already set-up MIOSQP model.
+
+    Every instance starts REPLICATED: all ranks hold the same single root and, the relaxations
+    being deterministic, visit the same nodes until at least `world` leaves are open; then the
+    leaves are dealt and each rank continues on its own.  Work done while replicated is counted
+    once (on rank 0) in `nodes` / `iters`."""
 
     def __init__(self, model, comm=None):
         self.model = model
@@ -75,24 +93,25 @@ class ShardedSearch(object):
         self.comm = comm if comm is not None else LocalComm()
         self.nodes = 0
         self.iters = 0
-        self.dealt = False
+        self.replicated = True
+        self.global_upper = np.inf
 
-    # every rank runs this part identically (same data, deterministic relaxations)
-    def expand_until(self, n_leaves, max_nodes=10 ** 9):
-        """Explore one node at a time, on every rank alike, until `n_leaves` leaves are open."""
-        w = self.work
-        rule = w.settings['tree_explor_rule']
-        done = 0
-        while 0 < len(w.leaves) < n_leaves and done < max_nodes:
-            self._visit(rule)
-            done += 1
-        return done
+    def begin_instance(self):
+        """Call after MIOSQP.update_vectors (new root on every rank)."""
+        self.replicated = True
+        self.global_upper = np.inf
+
+    def _count(self, leaf):
+        if not self.replicated or self.comm.rank == 0:
+            self.nodes += 1
+            self.iters += leaf.num_iter
 
     def deal(self):
         """Round-robin partition of the open leaves; rank r keeps leaves r, r+W, r+2W, ..."""
         w = self.work
         w.leaves = [lf for k, lf in enumerate(w.leaves) if k % self.comm.world == self.comm.rank]
-        self.dealt = True
+        self.replicated = False
+        self.global_upper = w.upper_glob
 
     def _visit(self, rule):
         w = self.work
@@ -100,25 +119,13 @@ class ShardedSearch(object):
         leaf.solve()
         w.bound_and_branch(leaf)
         w.iter_num += 1
-        self.nodes += 1
-        self.iters += leaf.num_iter
+        self._count(leaf)
         return leaf
 
-    def step(self, nodes_per_rank=1):
-        """One wave: up to `nodes_per_rank` local leaves, then the incumbent exchange."""
+    def _visit_wave(self, rule, width):
+        """Up to `width` local leaves in ONE batched relaxation call, taken in the order the
+        exploration rule would visit them, then bound/branch each in that order."""
         w = self.work
-        rule = w.settings['tree_explor_rule']
-        for _ in range(nodes_per_rank):
-            if not w.leaves:
-                break
-            self._visit(rule)
-        self.sync_incumbent()
-
-    def step_batched(self, width):
-        """One wave as ONE batched relaxation call: take up to `width` local leaves in the order the
-        exploration rule would visit them, solve them together, then bound/branch each in that order."""
-        w = self.work
-        rule = w.settings['tree_explor_rule']
         wave = []
         while w.leaves and len(wave) < width:
             wave.append(w.choose_leaf(rule))
@@ -127,28 +134,67 @@ class ShardedSearch(object):
             for leaf in wave:
                 w.bound_and_branch(leaf)
                 w.iter_num += 1
-                self.nodes += 1
-                self.iters += leaf.num_iter
-        self.sync_incumbent()
+                self._count(leaf)
+        return len(wave)
+
+    def expand_until(self, n_leaves, max_nodes=10 ** 9):
+        """Node-at-a-time exploration (identical on every rank while replicated) until
+        `n_leaves` leaves are open or the tree closes."""
+        w = self.work
+        rule = w.settings['tree_explor_rule']
+        done = 0
+        while 0 < len(w.leaves) < n_leaves and done < max_nodes:
+            self._visit(rule)
+            done += 1
+        return done
+
+    def step(self, nodes_per_rank=1, batched=False):
+        """One wave.  Returns the number of leaves open over all ranks afterwards."""
+        w = self.work
+        rule = w.settings['tree_explor_rule']
+        if self.replicated:
+            if len(w.leaves) >= self.comm.world or not w.leaves:
+                if w.leaves:
+                    self.deal()
+            else:
+                self._visit(rule)  # same node on every rank; nothing to exchange
+                return max(1, len(w.leaves)) if w.leaves else 0
+        if batched:
+            self._visit_wave(rule, nodes_per_rank)
+        else:
+            for _ in range(nodes_per_rank):
+                if not w.leaves:
+                    break
+                self._visit(rule)
+        return self.sync_incumbent()
+
+    def step_batched(self, width):
+        return self.step(width, batched=True)
 
     def sync_incumbent(self):
+        """Incumbent exchange + global open-leaf count (one all-gather, plus one broadcast only when
+        the incumbent improved somewhere)."""
         w = self.work
         if self.comm.world == 1:
-            return
-        best, owner, x = self.comm.incumbent(w.upper_glob, w.x)
-        if best < w.upper_glob:
-            w.upper_glob = best
-            w.x = x
-            w.prune()
+            return len(w.leaves)
+        best, owner, x, total = self.comm.exchange(w.upper_glob, w.x, len(w.leaves), self.global_upper)
+        if x is not None:
+            self.global_upper = best
+            if best < w.upper_glob:
+                w.upper_glob = best
+                w.x = x
+                w.prune()
+        return total
 
     def open_leaves(self):
         return int(self.comm.sum([len(self.work.leaves)])[0])
 
-    def run(self, nodes_per_rank=1, max_waves=10 ** 9):
+    def run(self, nodes_per_rank=1, max_waves=10 ** 9, batched=False):
         """Waves until no rank has leaves left (or max_waves)."""
         waves = 0
-        while waves < max_waves and self.open_leaves() > 0:
-            self.step(nodes_per_rank)
+        total = 1
+        while waves < max_waves and total > 0:
+            total = self.step(nodes_per_rank, batched)
             waves += 1
         w = self.work
         w.get_return_status()

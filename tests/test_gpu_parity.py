@@ -230,16 +230,37 @@ def test_config2_full_size_root_and_children(oracle_mod):
 
 
 def _wave_of_nodes(oracle_mod, pr, count):
-    """A realistic wave: nodes produced by actually branching (oracle-backed host search)."""
-    from miosqp_amd import bnb, dist
-    st = dict(problems.BNB_SETTINGS)
-    st["tree_explor_rule"] = 0
-    model = bnb.MIOSQP(backend=oracle_mod)
-    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
-                dict(problems.QP_SETTINGS))
-    s = dist.ShardedSearch(model)
-    s.expand_until(count)
-    return model.work.leaves[:count]
+    """A wave of distinct, realistic nodes: breadth-first branching (floor / ceil on the three most
+    fractional integers of every solved node) from the root, children warm-started from the parent."""
+    import types
+    A, l, u = problems.extended(pr)
+    n, M, m = A.shape[1], A.shape[0], pr["A"].shape[0]
+    o = oracle_mod.OSQP()
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    nodes = [types.SimpleNamespace(l=l.copy(), u=u.copy(), x=np.zeros(n), y=np.zeros(M))]
+    k = 0
+    ii = pr["i_idx"]
+    while len(nodes) < count and k < len(nodes):
+        nd = nodes[k]
+        k += 1
+        o.update(l=nd.l, u=nd.u)
+        o.warm_start(x=nd.x, y=nd.y)
+        r = o.solve()
+        if r.info.status_val != 1:
+            continue
+        frac = np.abs(r.x[ii] - np.round(r.x[ii]))
+        for v in np.argsort(-frac)[:3]:
+            if frac[v] < 1e-3:
+                continue
+            for side in (0, 1):
+                l2, u2 = nd.l.copy(), nd.u.copy()
+                if side == 0:
+                    u2[m + v] = np.floor(r.x[ii[v]])
+                else:
+                    l2[m + v] = np.ceil(r.x[ii[v]])
+                if np.all(l2 <= u2):
+                    nodes.append(types.SimpleNamespace(l=l2, u=u2, x=r.x.copy(), y=r.y.copy()))
+    return nodes[:count]
 
 
 @pytest.mark.parametrize("n,m,p,seed,count", [(20, 40, 10, 1, 7), (50, 100, 25, 2, 70), (130, 260, 65, 3, 130)])
