@@ -172,9 +172,10 @@ def main():
     if rank == 0:
         fs = eng.factor_stats()
         kern = []
-        for k in range(4):
+        names = ["k_fold_fwd", "k_fold_bwd"] if fs["fold"] else KERNELS
+        for k, nm in enumerate(names):
             us, by = eng.time_kernel(k, 300)
-            kern.append(dict(kernel=KERNELS[k], usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
+            kern.append(dict(kernel=nm, usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
         it_us, it_bytes = eng.time_kernel(4, 100)
         dom = max(kern, key=lambda d: d["usec"])
         roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
@@ -197,6 +198,8 @@ def main():
                                         "%d node(s) per rank per step, leaves sharded over %d GPU(s)" %
                                         (cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed, args.wave, world),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
+                               factor_form="product form L^-1 (2 launches/iteration)" if fs["fold"]
+                               else "L (4 launches/iteration)",
                                qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3)),
                    roofline=roof)
         out["config"]["instances_in_timed_region"] = instances

@@ -59,7 +59,9 @@ typedef struct miosqp_qp_settings {
   int32_t warm_start;        /* 1: solve() continues from the stored iterates */
   int32_t device;            /* HIP device ordinal; -1 = current device */
   int32_t max_batch;         /* capacity of miosqp_qp_solve_batch (>= 1) */
-  int32_t reserved[6];
+  int32_t fold;              /* -1 auto, 0 factor form L (4 kernels/iteration), 1 product form L^-1
+                                (2 kernels/iteration; auto picks it for panels denser than 30 %) */
+  int32_t reserved[5];
 } miosqp_qp_settings;
 
 /* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus
@@ -141,13 +143,15 @@ int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z
 int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
 
 /* sizes of the factor: out[0]=nnz(L) strict (panel + tail), out[1]=nnz panel, out[2]=tail order,
- * out[3]=algorithmic bytes per ADMM iteration (SURVEY.md sec. 8d formula), out[4..7] reserved */
+ * out[3]=algorithmic bytes per ADMM iteration (SURVEY.md sec. 8d formula), out[4..6] threads per
+ * row of the panel/tail kernels, out[7]=1 when the product-form factor is in use */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
 
 /* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's
  * own stream and returns the mean duration in microseconds in *usec and the kernel's
  * algorithmic bytes per launch in *bytes.  which: 0 panel-forward, 1 tail-forward,
- * 2 tail-backward, 3 panel-backward+update, 4 one whole ADMM iteration (all four);
+ * 2 tail-backward, 3 panel-backward+update, 4 one whole ADMM iteration (all four); with the
+ * product-form factor 0 = forward sweep, 1 = backward sweep + update, 2 and 3 are empty;
  * 10..14 the same for the batched kernels at full batch capacity (after a solve_batch). */
 int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, double *usec,
                           double *bytes);

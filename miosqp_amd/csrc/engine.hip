@@ -84,6 +84,10 @@ struct Dev {
   // staging: raw (unscaled) inputs and outputs
   double *raw_l, *raw_u, *raw_x, *raw_y, *out_x, *out_y;
   Ctrl *ctrl;
+  // ---- folded (product-form) factor: rows of L^-1, see factor.hpp ----
+  const double *f_rows, *f_GmT;
+  int ldf, ldn;
+  double *rx;  // sigma x - q, kept right behind wh so that [wh | rx] is one contiguous vector
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
   double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
@@ -168,7 +172,6 @@ __device__ __forceinline__ void prow_dot2(const int *__restrict__ idx, const dou
 // ------------------------------------------------------------------------------------------
 template <int TPR>
 __global__ __launch_bounds__(256) void k_panel_fwd(Dev d) {
-  if (d.ctrl->done) return;
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
@@ -180,7 +183,6 @@ __global__ __launch_bounds__(256) void k_panel_fwd(Dev d) {
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_tail_fwd(Dev d) {
-  if (d.ctrl->done) return;
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
@@ -200,7 +202,6 @@ __global__ __launch_bounds__(256) void k_tail_fwd(Dev d) {
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_tail_bwd(Dev d) {
-  if (d.ctrl->done) return;
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
@@ -228,7 +229,6 @@ __global__ __launch_bounds__(256) void k_tail_bwd(Dev d) {
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_panel_bwd(Dev d) {
-  if (d.ctrl->done) return;
   ROW_SETUP(TPR)
   const bool live = row_raw < d.M;
   const int row = live ? row_raw : d.M - 1;
@@ -243,6 +243,107 @@ __global__ __launch_bounds__(256) void k_panel_bwd(Dev d) {
     const double zr = alpha * zt + (1.0 - alpha) * zp;
     const double v = zr + yp / rho;
     const double zn = fmin(fmax(v, d.l[row]), d.u[row]);
+    const double dy = rho * (zr - zn);
+    const double yn = yp + dy;
+    d.z[row] = zn;
+    d.y[row] = yn;
+    d.dy[row] = dy;
+    d.wh[row] = zn - yn / rho;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// folded factor: the same iteration as TWO kernels (rows of L^-1, rows of L^-T)
+//   k_fold_fwd   ut = D22^-1 ( rx + [ -G | strict_lower(Linv) ] [wh ; rx] )          (n rows)
+//   k_fold_bwd   rows 0..n:   x~ = ut + strict_upper(Linv^T) ut ; x, dx, rx
+//                rows n..n+M: nu = -rho wh + (-G)^T ut ; z~, z, y, dy, wh
+// ------------------------------------------------------------------------------------------
+template <int TPR>
+__device__ __forceinline__ double drow_dot(const double *__restrict__ r, int len, const double *__restrict__ v,
+                                           int t) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int len2 = len & ~1;
+  int j = 2 * t;
+  for (; j + 2 * TPR < len2; j += 4 * TPR) {
+    const double2 a = *reinterpret_cast<const double2 *>(r + j);
+    const double2 b = *reinterpret_cast<const double2 *>(v + j);
+    const double2 c = *reinterpret_cast<const double2 *>(r + j + 2 * TPR);
+    const double2 e = *reinterpret_cast<const double2 *>(v + j + 2 * TPR);
+    a0 = fma(a.x, b.x, a0);
+    a1 = fma(a.y, b.y, a1);
+    a2 = fma(c.x, e.x, a2);
+    a3 = fma(c.y, e.y, a3);
+  }
+  if (j < len2) {
+    const double2 a = *reinterpret_cast<const double2 *>(r + j);
+    const double2 b = *reinterpret_cast<const double2 *>(v + j);
+    a0 = fma(a.x, b.x, a0);
+    a1 = fma(a.y, b.y, a1);
+  }
+  if (t == 0 && (len & 1)) a2 = fma(r[len - 1], v[len - 1], a2);
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int TPR>
+__global__ __launch_bounds__(256) void k_fold_fwd(Dev d) {
+  ROW_SETUP(TPR)
+  const bool live = row_raw < d.n;
+  const int row = live ? row_raw : d.n - 1;
+  const double rxi = d.rx[row], di = d.d2inv[row];
+  double acc[1];
+  acc[0] = drow_dot<TPR>(d.f_rows + (size_t)row * d.ldf, d.M + row, d.wh, t);
+  row_reduce<TPR, 1>(acc, lds);
+  if (live && t == 0) d.ut[row] = di * (rxi + acc[0]);
+}
+
+template <int TPR_X, int TPR_C>
+__global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
+  __shared__ double lds[16];
+  const int n = d.n;
+  constexpr int RPX = 256 / TPR_X, RPC = 256 / TPR_C;
+  const int nbx = (n + RPX - 1) / RPX;
+  if ((int)blockIdx.x < nbx) {
+    const int row_raw = blockIdx.x * RPX + threadIdx.x / TPR_X;
+    const int t = threadIdx.x % TPR_X;
+    const bool live = row_raw < n;
+    const int row = live ? row_raw : n - 1;
+    const double *__restrict__ Ur = d.LinvT + (size_t)row * d.ld;
+    const double *__restrict__ u = d.ut;
+    const double ui = u[row], xp = d.x[row], qi = d.q[row];
+    double a0 = 0.0, a1 = 0.0;
+    int j = row + 1 + t;
+    for (; j + TPR_X < n; j += 2 * TPR_X) {
+      a0 = fma(Ur[j], u[j], a0);
+      a1 = fma(Ur[j + TPR_X], u[j + TPR_X], a1);
+    }
+    if (j < n) a0 = fma(Ur[j], u[j], a0);
+    double acc[1] = {a0 + a1};
+    row_reduce<TPR_X, 1>(acc, lds);
+    if (live && t == 0) {
+      const double xt = ui + acc[0];
+      const double xn = d.alpha * xt + (1.0 - d.alpha) * xp;
+      d.xt[row] = xt;
+      d.x[row] = xn;
+      d.dx[row] = xn - xp;
+      d.rx[row] = d.sigma * xn - qi;
+    }
+    return;
+  }
+  const int row_raw = (blockIdx.x - nbx) * RPC + threadIdx.x / TPR_C;
+  const int t = threadIdx.x % TPR_C;
+  const bool live = row_raw < d.M;
+  const int row = live ? row_raw : d.M - 1;
+  const double whj = d.wh[row], zp = d.z[row], yp = d.y[row], lj = d.l[row], uj = d.u[row];
+  double acc[1];
+  acc[0] = drow_dot<TPR_C>(d.f_GmT + (size_t)row * d.ldn, n, d.ut, t);
+  row_reduce<TPR_C, 1>(acc, lds);
+  if (live && t == 0) {
+    const double rho = d.rho, alpha = d.alpha;
+    const double nu = -rho * whj + acc[0];
+    const double zt = zp + (nu - yp) / rho;
+    const double zr = alpha * zt + (1.0 - alpha) * zp;
+    const double v = zr + yp / rho;
+    const double zn = fmin(fmax(v, lj), uj);
     const double dy = rho * (zr - zn);
     const double yn = yp + dy;
     d.z[row] = zn;
@@ -497,6 +598,7 @@ __global__ __launch_bounds__(256) void k_warm_z(Dev d) {
 __global__ void k_init_wh(Dev d) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < d.M) d.wh[j] = d.z[j] - d.y[j] / d.rho;
+  if (j < d.n) d.rx[j] = d.sigma * d.x[j] - d.q[j];
 }
 
 // one workgroup: unscale the answer (or build the certificate), then the integer clamp of
@@ -994,6 +1096,8 @@ struct miosqp_qp_engine {
   Ctrl *h_ctrl = nullptr;
   double *d_in = nullptr;
   bool have_int = false;
+  bool fold = false;
+  miosqp::Folded fo;
   int64_t nnzA = 0, nnzPtriu = 0;
   // batched mode
   int Bcap = 0;  // capacity (columns), multiple of 64; 0 = batched mode not allocated
@@ -1027,6 +1131,12 @@ int dupload(miosqp_qp_engine *e, const std::vector<T> &h, const T **p) {
 
 void launch_iteration(miosqp_qp_engine *e) {
   const Dev &d = e->d;
+  if (e->fold) {
+    hipLaunchKernelGGL(k_fold_fwd<256>, dim3(d.n), dim3(256), 0, e->stream, d);
+    const int nb = (d.n + 3) / 4 + (d.M + 3) / 4;
+    hipLaunchKernelGGL((k_fold_bwd<64, 64>), dim3(nb), dim3(256), 0, e->stream, d);
+    return;
+  }
   DISPATCH_TPR(e->tpr_pv, k_panel_fwd, d.n, e->stream, d);
   DISPATCH_TPR(e->tpr_tail, k_tail_fwd, d.n, e->stream, d);
   DISPATCH_TPR(e->tpr_tail, k_tail_bwd, d.n, e->stream, d);
@@ -1248,6 +1358,7 @@ int miosqp_qp_default_settings(miosqp_qp_settings *s) {
   s->warm_start = 1;
   s->device = -1;
   s->max_batch = 1;
+  s->fold = -1;
   return 0;
 }
 
@@ -1350,8 +1461,9 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     int rc__ = dalloc(e, &d.field, (size_t)(count));     \
     if (rc__) { miosqp_qp_cleanup(e); return rc__; }     \
   } while (0)
-  AL(q, n); AL(qraw, n); AL(l, M); AL(u, M); AL(x, n); AL(z, M); AL(y, M); AL(wh, M); AL(cv, n); AL(ut, n);
+  AL(q, n); AL(qraw, n); AL(l, M); AL(u, M); AL(x, n); AL(z, M); AL(y, M); AL(wh, (size_t)M + n); AL(cv, n); AL(ut, n);
   AL(xt, n); AL(dx, n); AL(dy, M); AL(sm, 8 * (size_t)M); AL(sn, 10 * (size_t)n);
+  d.rx = d.wh + M;
   AL(ctrl, 1);
   // staging block: raw_l | raw_u | raw_x | raw_y contiguous, out_x | out_y contiguous
   AL(raw_l, 2 * (size_t)M + n + M);
@@ -1387,6 +1499,24 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->tpr_tail = pick_tpr(0.5 * n);
   e->tpr_pb = pick_tpr((double)f.Pbar.nnz / n);
   e->tpr_pr = pick_tpr((double)f.Praw.nnz / n);
+  {
+    // product-form factor: worth it when the panel is dense (bytes no worse, half the launches)
+    const double dens = M > 0 ? (double)f.nnz_panel / ((double)n * M) : 0.0;
+    const double fold_bytes = 8.0 * ((double)n * (M + n) + (double)M * n);
+    int want = s->fold;
+    if (want < 0) want = (M > 0 && dens >= 0.30 && fold_bytes <= 4.0e9) ? 1 : 0;
+    if (want && M > 0) {
+      miosqp::build_folded(f, e->fo);
+      int rc = dupload(e, e->fo.rows, &d.f_rows);
+      if (!rc) rc = dupload(e, e->fo.GmT, &d.f_GmT);
+      if (rc) { miosqp_qp_cleanup(e); return rc; }
+      d.ldf = e->fo.ldf;
+      d.ldn = e->fo.ldn;
+      e->fold = true;
+      std::vector<double>().swap(e->fo.rows);
+      std::vector<double>().swap(e->fo.GmT);
+    }
+  }
   e->chunk = e->st.check_termination;
   e->tail_iters = e->st.max_iter % e->chunk;
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1442,7 +1572,7 @@ static int begin_solve(miosqp_qp_engine *e) {
   HIPCHK(hipEventRecord(e->ev0, e->stream));
   if (!e->st.warm_start) hipLaunchKernelGGL(k_zero_iterates, dim3((big + 255) / 256), dim3(256), 0, e->stream, e->d);
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, e->d);
-  hipLaunchKernelGGL(k_init_wh, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, e->d);
+  hipLaunchKernelGGL(k_init_wh, dim3(((e->M > e->n ? e->M : e->n) + 255) / 256), dim3(256), 0, e->stream, e->d);
   return 0;
 }
 
@@ -1490,7 +1620,7 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, 
   hipLaunchKernelGGL(k_scale_bounds, dim3((M + 255) / 256), dim3(256), 0, e->stream, e->d);
   enqueue_warm(e);
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, e->d);
-  hipLaunchKernelGGL(k_init_wh, dim3((M + 255) / 256), dim3(256), 0, e->stream, e->d);
+  hipLaunchKernelGGL(k_init_wh, dim3(((M > n ? M : n) + 255) / 256), dim3(256), 0, e->stream, e->d);
   int rc = run_loop(e);
   if (!rc) rc = finish_and_fetch(e, 1, x_out, y_out, info, t0);
   return rc;
@@ -1524,7 +1654,7 @@ int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const
 int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z, double *y) {
   if (!e || k < 0) return MIOSQP_EARG;
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, e->d);
-  hipLaunchKernelGGL(k_init_wh, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, e->d);
+  hipLaunchKernelGGL(k_init_wh, dim3(((e->M > e->n ? e->M : e->n) + 255) / 256), dim3(256), 0, e->stream, e->d);
   for (int i = 0; i < k; i++) launch_iteration(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   if (x) HIPCHK(hipMemcpy(x, e->d.x, sizeof(double) * e->n, hipMemcpyDeviceToHost));
@@ -1562,7 +1692,7 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[1] = e->fa.nnz_panel;
   out[2] = e->n;
   out[3] = (int64_t)b[4];
-  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = 0;
+  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = e->fold ? 1 : 0;
   return 0;
 }
 
@@ -1601,6 +1731,12 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
   if (which >= 10) hipLaunchKernelGGL(kb_reset, dim3((d.Bs + 255) / 256), dim3(256), 0, e->stream, d, e->Bcap);
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, d);
   auto one = [&]() {
+    if (e->fold && which < 4) {
+      if (which == 0) hipLaunchKernelGGL(k_fold_fwd<256>, dim3(d.n), dim3(256), 0, e->stream, d);
+      if (which == 1)
+        hipLaunchKernelGGL((k_fold_bwd<64, 64>), dim3((d.n + 3) / 4 + (d.M + 3) / 4), dim3(256), 0, e->stream, d);
+      return;
+    }
     switch (which) {
       case 10: hipLaunchKernelGGL(kb_panel_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
       case 11: hipLaunchKernelGGL(kb_tail_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
@@ -1627,6 +1763,8 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
     kernel_bytes(e, b);
     if (which < 10) {
       *bytes = b[which];
+      if (e->fold && which < 4)  // forward sweep = panel + tail forward, backward likewise
+        *bytes = which == 0 ? b[0] + b[1] : which == 1 ? b[2] + b[3] : 0.0;
     } else {
       // batched: matrix terms once per launch, per-node vector terms times the columns
       const double n = e->n, M = e->M, np = (double)e->fa.nnz_panel, nt = (double)e->fa.nnz_tail, B = e->Bcap;

@@ -314,4 +314,30 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
   return true;
 }
 
+void build_folded(const Factor &f, Folded &o) {
+  const int n = f.n, M = f.M, ld = f.ld;
+  o.n = n;
+  o.M = M;
+  o.ldf = (M + n + 7) & ~7;
+  o.ldn = (n + 7) & ~7;
+  o.rows.assign((size_t)n * o.ldf, 0.0);
+  o.GmT.assign((size_t)(M > 0 ? M : 1) * o.ldn, 0.0);
+  const PCsr &R = f.panel_by_var;  // rows of L21
+  // row i of -G = -( L21[i][:] + sum_{j<i} Linv[i][j] L21[j][:] ), accumulated densely
+  parallel_chunks(n, (int64_t)n * 200 + 1, [&](int64_t ii) {
+    const int i = (int)ii;
+    double *g = &o.rows[(size_t)i * o.ldf];
+    for (int k = R.ptr[i]; k < R.ptr[i + 1]; k++) g[R.idx[k]] -= R.val[k];
+    const double *Li = &f.Linv[(size_t)i * ld];
+    for (int j = 0; j < i; j++) {
+      const double w = Li[j];
+      if (w == 0.0) continue;
+      for (int k = R.ptr[j]; k < R.ptr[j + 1]; k++) g[R.idx[k]] -= w * R.val[k];
+    }
+    for (int j = 0; j < i; j++) g[M + j] = Li[j];
+  });
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < M; j++) o.GmT[(size_t)j * o.ldn + i] = o.rows[(size_t)i * o.ldf + j];
+}
+
 }  // namespace miosqp

@@ -62,6 +62,17 @@ struct Factor {
   int64_t nnz_panel = 0, nnz_tail = 0;
 };
 
+// Product form of the factor ("folded"): L^-1 = [ I 0 ; -G  Linv ] with G = L22^-1 L21 dense.
+// Chosen when the panel is dense enough that G costs no more bytes than the two sparse copies
+// of L21 (12 B/entry at ~70 % density vs 8 B/entry dense): both triangular sweeps then need ONE
+// row-parallel kernel each instead of two (panel + tail), halving the launches per iteration.
+struct Folded {
+  int n = 0, M = 0, ldf = 0, ldn = 0;
+  std::vector<double> rows;  // n x ldf row-major: row i = [ -G[i][0..M) | Linv[i][0..i) | 0.. ]
+  std::vector<double> GmT;   // M x ldn row-major: GmT[j][i] = -G[i][j]
+};
+void build_folded(const Factor &f, Folded &out);
+
 // Ruiz equilibration + cost normalisation (OSQP paper sec. 5.1).  P: CSC, only row<=col read.
 void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
                    const int32_t *Ap, const int32_t *Ai, const double *Ax, const double *q,

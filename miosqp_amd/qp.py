@@ -190,7 +190,8 @@ class OSQP(object):
         _check(self._lib.miosqp_qp_get_factor_stats(self._h, out.ctypes.data_as(_lib.i64p)),
                "get_factor_stats")
         return dict(nnz_L=int(out[0]), nnz_panel=int(out[1]), tail_order=int(out[2]),
-                    bytes_per_iter=int(out[3]), tpr=(int(out[4]), int(out[5]), int(out[6])))
+                    bytes_per_iter=int(out[3]), tpr=(int(out[4]), int(out[5]), int(out[6])),
+                    fold=bool(out[7]))
 
     def loop_stats(self, reset=False):
         ms, it = C.c_double(), C.c_int64()

@@ -92,6 +92,33 @@ void hh_apply_kinv(void *p, const double *rx, const double *rz, double *xt, doub
   for (int j = 0; j < M; j++) nu[j] = -f.rho * rz[j] - prow(f.panel_by_con, f.panel_by_con.val, j, xt);
 }
 
+// the same K^-1 through the product-form factor (engine.hip: k_fold_fwd, k_fold_bwd)
+void hh_apply_kinv_folded(void *p, const double *rx, const double *rz, double *xt, double *nu) {
+  Harness *h = (Harness *)p;
+  const Factor &f = h->fa;
+  Folded fo;
+  build_folded(f, fo);
+  int n = f.n, M = f.M;
+  std::vector<double> b(M + n), u(n);
+  for (int j = 0; j < M; j++) b[j] = rz[j];
+  for (int i = 0; i < n; i++) b[M + i] = rx[i];
+  for (int i = 0; i < n; i++) {
+    double s = rx[i];
+    for (int k = 0; k < M + i; k++) s += fo.rows[(size_t)i * fo.ldf + k] * b[k];
+    u[i] = f.d2inv[i] * s;
+  }
+  for (int i = 0; i < n; i++) {
+    double s = u[i];
+    for (int j = i + 1; j < n; j++) s += f.LinvT[(size_t)i * f.ld + j] * u[j];
+    xt[i] = s;
+  }
+  for (int j = 0; j < M; j++) {
+    double s = -f.rho * rz[j];
+    for (int i = 0; i < n; i++) s += fo.GmT[(size_t)j * fo.ldn + i] * u[i];
+    nu[j] = s;
+  }
+}
+
 // y = Abar x via the by-constraint rows, w = Abar' v via the by-variable rows, t = Pbar x
 void hh_products(void *p, const double *x, const double *v, double *Ax, double *Atv, double *Px, double *Praw_x) {
   Harness *h = (Harness *)p;

@@ -323,3 +323,37 @@ def test_batched_search_finds_the_same_optimum():
     assert abs(out[0][1] - out[1][1]) <= 1e-3 * max(1.0, abs(out[0][1]))
     ii = pr["i_idx"]
     np.testing.assert_array_equal(out[0][2][ii], out[1][2][ii])
+
+
+@pytest.mark.parametrize("fold", [0, 1])
+def test_both_factor_forms_match_oracle(oracle_mod, fold):
+    """fold=0: factor form L (4 kernels per iteration); fold=1: product form L^-1 (2 kernels)."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(60, 120, 30, seed=11)
+    A, l, u = problems.extended(pr)
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, **problems.QP_SETTINGS)
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    assert g.factor_stats()["fold"] == bool(fold)
+    rng = np.random.RandomState(3)
+    x0, y0 = rng.randn(60), rng.randn(A.shape[0])
+    for k in (1, 3, 40):
+        g.warm_start(x=x0, y=y0)
+        o.warm_start(x=x0, y=y0)
+        xg, zg, yg = g.debug_iterate(k)
+        o.iterate(k)
+        xo, zo, yo = o.iterates()
+        assert rel(xg, xo) <= ITER_TOL and rel(zg, zo) <= ITER_TOL and rel(yg, yo) <= ITER_TOL, k
+    g.warm_start(x=x0, y=y0)
+    o.warm_start(x=x0, y=y0)
+    rg, ro = g.solve(), o.solve()
+    assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
+    assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL
+    # a new linear cost keeps the factor (solver.py:183-185)
+    q2 = pr["q"] + 0.5 * rng.randn(60)
+    for s_ in (g, o):
+        s_.update(q=q2)
+        s_.warm_start(x=np.zeros(60), y=np.zeros(A.shape[0]))
+    rg, ro = g.solve(), o.solve()
+    assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
+    assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL

@@ -36,6 +36,7 @@ def hh(tmp_path_factory):
     L.hh_nnz_panel.argtypes = [C.c_void_p]
     L.hh_nnz_panel.restype = C.c_long
     L.hh_apply_kinv.argtypes = [C.c_void_p, dp, dp, dp, dp]
+    L.hh_apply_kinv_folded.argtypes = [C.c_void_p, dp, dp, dp, dp]
     L.hh_products.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp]
     return L
 
@@ -93,6 +94,11 @@ def test_block_factor_matches_dense_solve(hh, oracle_mod, n, m, p, seed):
         scale = np.max(np.abs(ref))
         assert np.max(np.abs(xt - ref[:n])) <= 1e-9 * scale
         assert np.max(np.abs(nu - ref[n:])) <= 1e-9 * scale
+        # product-form factor gives the same K^-1
+        xt2, nu2 = np.empty(n), np.empty(M)
+        hh.hh_apply_kinv_folded(h, _d(rx), _d(rz), _d(xt2), _d(nu2))
+        assert np.max(np.abs(xt2 - ref[:n])) <= 1e-9 * scale
+        assert np.max(np.abs(nu2 - ref[n:])) <= 1e-9 * scale
         # tail: Linv is the inverse of the unit-lower factor of S = Pb + sigma I + rho Ab'Ab
         Linv, LinvT, d2inv = np.empty((n, n)), np.empty((n, n)), np.empty(n)
         hh.hh_tail(h, _d(Linv), _d(LinvT), _d(d2inv))
