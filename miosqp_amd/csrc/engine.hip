@@ -90,7 +90,7 @@ struct Dev {
   double *rx;  // sigma x - q, kept right behind wh so that [wh | rx] is one contiguous vector
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
-  double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
+  double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_rx, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
   double *b_sm, *b_sn;      // 8 x M x Bs, 4 x n x Bs
   double *b_xfin, *b_yfin;  // unscaled answers, batch-fastest
   double *b_raw;            // node-major staging in:  l[B][M] | u[B][M] | x0[B][n] | y0[B][M]
@@ -825,6 +825,155 @@ __global__ __launch_bounds__(256) void kb_check_var(Dev d) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// batched mode on the product-form factor: dense row blocks.  One workgroup = 8 waves =
+// 4 row groups x 2 halves of the k range; a wave owns 2 rows x 64 nodes.  The right-hand tile
+// V[k0..k0+16)[64 nodes] is staged once per workgroup in LDS (double-buffered, next tile's global
+// loads in flight during the FMAs), matrix entries are wave-uniform scalar loads, each LDS value
+// feeds both rows.  The two k halves are added in LDS in a fixed order.
+// ------------------------------------------------------------------------------------------
+constexpr int BD_KT = 16, BD_R = 2, BD_RG = 4, BD_ROWS = BD_R * BD_RG;  // 8 rows per workgroup
+
+__device__ __forceinline__ void bd_dot(const double *__restrict__ A, int ld, int nrows, int row0, int kbeg,
+                                       int kend, const double *__restrict__ V, size_t Bs, double *lds,
+                                       double (&acc)[BD_R]) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rg = w & 3, kh = w >> 2;
+  const int k0 = kbeg & ~(BD_KT - 1);
+  const int nt_half = ((kend - k0 + BD_KT - 1) / BD_KT + 1) / 2;
+  const int kstart = k0 + kh * nt_half * BD_KT;
+  double *buf = lds + kh * (2 * BD_KT * 64);
+  int ra = row0 + rg * BD_R, rb = ra + 1;
+  ra = ra < nrows ? ra : nrows - 1;
+  rb = rb < nrows ? rb : nrows - 1;
+  const double *__restrict__ a0 = A + (size_t)ra * ld;
+  const double *__restrict__ a1 = A + (size_t)rb * ld;
+  acc[0] = acc[1] = 0.0;
+  double p[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int k = kstart + rg + 4 * i;
+    p[i] = k < kend ? V[(size_t)k * Bs] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) buf[(rg + 4 * i) * 64 + lane] = p[i];
+  __syncthreads();
+  for (int t = 0; t < nt_half; t++) {
+    const int kt = kstart + t * BD_KT;
+    const bool more = t + 1 < nt_half;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int k = kt + BD_KT + rg + 4 * i;
+        p[i] = k < kend ? V[(size_t)k * Bs] : 0.0;
+      }
+    }
+    const double *cur = buf + (t & 1) * (BD_KT * 64);
+#pragma unroll
+    for (int kk = 0; kk < BD_KT; kk++) {
+      const double v = cur[kk * 64 + lane];
+      acc[0] = fma(a0[kt + kk], v, acc[0]);
+      acc[1] = fma(a1[kt + kk], v, acc[1]);
+    }
+    if (more) {
+      double *nxt = buf + ((t + 1) & 1) * (BD_KT * 64);
+#pragma unroll
+      for (int i = 0; i < 4; i++) nxt[(rg + 4 * i) * 64 + lane] = p[i];
+    }
+    __syncthreads();
+  }
+  // add the second half of the k range (fixed order: first half + second half)
+  double *red = lds + 4 * BD_KT * 64;
+  if (kh == 1) {
+    red[(rg * BD_R + 0) * 64 + lane] = acc[0];
+    red[(rg * BD_R + 1) * 64 + lane] = acc[1];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    acc[0] += red[(rg * BD_R + 0) * 64 + lane];
+    acc[1] += red[(rg * BD_R + 1) * 64 + lane];
+  }
+}
+
+// ut = D22^-1 ( rx + [ -G | strict_lower(Linv) ] [wh ; rx] ), rows of L^-1
+__global__ __launch_bounds__(512) void kbd_fwd(Dev d) {
+  if (d.ctrl->done) return;
+  __shared__ double lds[4 * BD_KT * 64 + BD_ROWS * 64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t Bs = (size_t)d.Bs;
+  const int b = blockIdx.y * 64 + lane;
+  const int row0 = blockIdx.x * BD_ROWS;
+  int kend = d.M + row0 + BD_ROWS;
+  if (kend > d.M + d.n) kend = d.M + d.n;
+  double acc[BD_R];
+  bd_dot(d.f_rows, d.ldf, d.n, row0, 0, kend, d.b_wh + b, Bs, lds, acc);
+  if (w >= 4) return;
+#pragma unroll
+  for (int r = 0; r < BD_R; r++) {
+    const int row = row0 + w * BD_R + r;
+    if (row < d.n) d.b_ut[row * Bs + b] = d.d2inv[row] * (d.b_rx[row * Bs + b] + acc[r]);
+  }
+}
+
+// rows of L^-T: blocks [0, nbx) the x rows (strict upper Linv^T), the rest the constraint rows (-G)^T
+__global__ __launch_bounds__(512) void kbd_bwd(Dev d) {
+  if (d.ctrl->done) return;
+  __shared__ double lds[4 * BD_KT * 64 + BD_ROWS * 64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t Bs = (size_t)d.Bs;
+  const int b = blockIdx.y * 64 + lane;
+  const int nbx = (d.n + BD_ROWS - 1) / BD_ROWS;
+  double acc[BD_R];
+  if ((int)blockIdx.x < nbx) {
+    const int row0 = blockIdx.x * BD_ROWS;
+    bd_dot(d.LinvT, d.ld, d.n, row0, row0 + 1, d.n, d.b_ut + b, Bs, lds, acc);
+    if (w >= 4) return;
+    const bool frozen = d.c_done[b] != 0;
+#pragma unroll
+    for (int r = 0; r < BD_R; r++) {
+      const int row = row0 + w * BD_R + r;
+      if (row >= d.n) continue;
+      const size_t o = row * Bs + b;
+      const double xt = d.b_ut[o] + acc[r];
+      d.b_xt[o] = xt;
+      if (!frozen) {
+        const double xp = d.b_x[o];
+        const double xn = d.alpha * xt + (1.0 - d.alpha) * xp;
+        d.b_x[o] = xn;
+        d.b_dx[o] = xn - xp;
+        d.b_rx[o] = d.sigma * xn - d.q[row];
+      }
+    }
+    return;
+  }
+  const int row0 = (blockIdx.x - nbx) * BD_ROWS;
+  bd_dot(d.f_GmT, d.ldn, d.M, row0, 0, d.n, d.b_ut + b, Bs, lds, acc);
+  if (w >= 4) return;
+  if (d.c_done[b]) return;
+  const double rho = d.rho, alpha = d.alpha;
+#pragma unroll
+  for (int r = 0; r < BD_R; r++) {
+    const int row = row0 + w * BD_R + r;
+    if (row >= d.M) continue;
+    const size_t o = row * Bs + b;
+    const double zp = d.b_z[o], yp = d.b_y[o];
+    const double nu = -rho * d.b_wh[o] + acc[r];
+    const double zt = zp + (nu - yp) / rho;
+    const double zr = alpha * zt + (1.0 - alpha) * zp;
+    const double v = zr + yp / rho;
+    const double zn = fmin(fmax(v, d.b_l[o]), d.b_u[o]);
+    const double dy = rho * (zr - zn);
+    const double yn = yp + dy;
+    d.b_z[o] = zn;
+    d.b_y[o] = yn;
+    d.b_dy[o] = dy;
+    d.b_wh[o] = zn - yn / rho;
+  }
+}
+
 // column-wise reductions: 1024 threads = 64 columns x 16 row groups; fixed order
 #define COLRED(name, OP, init)                                                          \
   __device__ __forceinline__ double name(double v, double *lds, int bl, int rg) {       \
@@ -952,8 +1101,10 @@ __global__ __launch_bounds__(256) void kb_prepare(Dev d, int B) {
   }
   if (j < d.n) {
     const size_t o = j * Bs + b;
-    d.b_x[o] = act ? d.Dinv[j] * rx[(size_t)b * n + j] : 0.0;
+    const double xs = act ? d.Dinv[j] * rx[(size_t)b * n + j] : 0.0;
+    d.b_x[o] = xs;
     d.b_dx[o] = 0.0;
+    d.b_rx[o] = d.sigma * xs - d.q[j];
   }
 }
 
@@ -1068,8 +1219,9 @@ inline int pick_tpr(double avg_row) {
 
 template <typename T>
 int upload(const std::vector<T> &h, T **dptr) {
-  size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
+  size_t bytes = (h.size() + 64) * sizeof(T);  // zeroed slack: tile loads may overshoot the last row
   HIPCHK(hipMalloc((void **)dptr, bytes));
+  HIPCHK(hipMemset(*dptr, 0, bytes));
   if (h.size()) HIPCHK(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   return 0;
 }
@@ -1215,6 +1367,12 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
 // ---- batched mode (host) -------------------------------------------------------------------
 void launch_iteration_b(miosqp_qp_engine *e, int ntiles) {
   const Dev &d = e->d;
+  if (e->fold) {
+    const int nbx = (d.n + BD_ROWS - 1) / BD_ROWS, nbc = (d.M + BD_ROWS - 1) / BD_ROWS;
+    hipLaunchKernelGGL(kbd_fwd, dim3(nbx, ntiles), dim3(512), 0, e->stream, d);
+    hipLaunchKernelGGL(kbd_bwd, dim3(nbx + nbc, ntiles), dim3(512), 0, e->stream, d);
+    return;
+  }
   hipLaunchKernelGGL(kb_panel_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_tail_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_tail_bwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
@@ -1244,13 +1402,14 @@ int alloc_batch(miosqp_qp_engine *e, int cap) {
     int rc__ = dalloc(e, &d.field, (size_t)(count)); \
     if (rc__) return rc__;                           \
   } while (0)
-  ALB(b_l, M * Bs); ALB(b_u, M * Bs); ALB(b_x, n * Bs); ALB(b_z, M * Bs); ALB(b_y, M * Bs); ALB(b_wh, M * Bs);
+  ALB(b_l, M * Bs); ALB(b_u, M * Bs); ALB(b_x, n * Bs); ALB(b_z, M * Bs); ALB(b_y, M * Bs); ALB(b_wh, (M + n) * Bs);
   ALB(b_cv, n * Bs); ALB(b_ut, n * Bs); ALB(b_xt, n * Bs); ALB(b_dx, n * Bs); ALB(b_dy, M * Bs);
   ALB(b_sm, 8 * M * Bs); ALB(b_sn, 4 * n * Bs); ALB(b_xfin, n * Bs); ALB(b_yfin, M * Bs);
   ALB(b_raw, Bs * (3 * M + n)); ALB(b_out, Bs * (n + M));
   ALB(c_done, Bs); ALB(c_status, Bs); ALB(c_iter, Bs); ALB(c_pri, Bs); ALB(c_dua, Bs); ALB(c_obj, Bs);
   ALB(c_lower, Bs);
 #undef ALB
+  d.b_rx = d.b_wh + M * Bs;
   HIPCHK(hipHostMalloc((void **)&e->hb_in, sizeof(double) * Bs * (3 * M + n), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->hb_out, sizeof(double) * Bs * (n + M), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->hb_int, sizeof(int) * 2 * Bs, hipHostMallocDefault));
@@ -1737,6 +1896,12 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
         hipLaunchKernelGGL((k_fold_bwd<64, 64>), dim3((d.n + 3) / 4 + (d.M + 3) / 4), dim3(256), 0, e->stream, d);
       return;
     }
+    if (e->fold && which >= 10 && which < 14) {
+      const int nbx = (d.n + BD_ROWS - 1) / BD_ROWS, nbc = (d.M + BD_ROWS - 1) / BD_ROWS;
+      if (which == 10) hipLaunchKernelGGL(kbd_fwd, dim3(nbx, ntiles), dim3(512), 0, e->stream, d);
+      if (which == 11) hipLaunchKernelGGL(kbd_bwd, dim3(nbx + nbc, ntiles), dim3(512), 0, e->stream, d);
+      return;
+    }
     switch (which) {
       case 10: hipLaunchKernelGGL(kb_panel_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
       case 11: hipLaunchKernelGGL(kb_tail_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d); break;
@@ -1772,6 +1937,9 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
                              np * 12 + (M + 1) * 4, 2 * (np + nt) * 12 + 2 * (n + M + 1) * 4 + (n + M) * 12};
       const double vec[5] = {(M + 3 * n) * 8, 3 * n * 8, 5 * n * 8, (n + 10 * M) * 8, (6 * n + 16 * M) * 8};
       *bytes = mat[which - 10] + B * vec[which - 10];
+      if (e->fold && which < 14)
+        *bytes = which == 10 ? mat[0] + mat[1] + B * (vec[0] + vec[1])
+                 : which == 11 ? mat[2] + mat[3] + B * (vec[2] + vec[3]) : 0.0;
     }
   }
   return 0;

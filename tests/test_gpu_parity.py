@@ -263,8 +263,10 @@ def _wave_of_nodes(oracle_mod, pr, count):
     return nodes[:count]
 
 
-@pytest.mark.parametrize("n,m,p,seed,count", [(20, 40, 10, 1, 7), (50, 100, 25, 2, 70), (130, 260, 65, 3, 130)])
-def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count):
+@pytest.mark.parametrize("n,m,p,seed,count,fold", [(20, 40, 10, 1, 7, -1), (50, 100, 25, 2, 70, 0),
+                                                    (50, 100, 25, 2, 70, 1), (130, 260, 65, 3, 130, -1),
+                                                    (37, 3, 5, 4, 9, 1)])
+def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold):
     """solve_batch on a wave of real B&B leaves == solve_node on each == the oracle."""
     from miosqp_amd import qp
     pr = problems.random_miqp(n, m, p, seed=seed)
@@ -272,7 +274,7 @@ def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count):
     assert len(leaves) >= 2
     A, l, u = problems.extended(pr)
     g, o = qp.OSQP(), oracle_mod.OSQP()
-    g.setup(pr["P"], pr["q"], A, l, u, max_batch=64, **problems.QP_SETTINGS)  # 64 < count: slices
+    g.setup(pr["P"], pr["q"], A, l, u, max_batch=64, fold=fold, **problems.QP_SETTINGS)  # 64 < count: slices
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
     g.set_integer_rows(pr["i_idx"], m)
     L = np.stack([lf.l for lf in leaves]); U = np.stack([lf.u for lf in leaves])
