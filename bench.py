@@ -31,6 +31,20 @@ KERNELS = ["k_panel_fwd", "k_tail_fwd", "k_tail_bwd", "k_panel_bwd"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/
+    r*_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1]))["kernels"].get(kernel)
+        return None if rec is None else rec["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(prob, budget_s):
     """The CPU oracle ("port": own restatement, NOT the real OSQP which is absent) on the same tree,
     one thread, bounded to about `budget_s` seconds."""
@@ -179,7 +193,8 @@ def main():
         it_us, it_bytes = eng.time_kernel(4, 100)
         dom = max(kern, key=lambda d: d["usec"])
         roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom["kernel"]),
+                    traffic_source="profiles/r*_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
                     bytes_per_launch=dom["bytes"], usec_per_launch=dom["usec"], kernels=kern,
                     iteration=dict(bytes=fs["bytes_per_iter"],
                                    usec_in_timed_region=round(1e3 * loop_ms / max(1, loop_iters), 3),

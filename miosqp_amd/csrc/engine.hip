@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -88,6 +89,7 @@ struct Dev {
   const double *f_rows, *f_GmT;
   int ldf, ldn;
   double *rx;  // sigma x - q, kept right behind wh so that [wh | rx] is one contiguous vector
+  unsigned long long *prof;  // debug timeline (per-block start/end, 100 MHz wall clock) or nullptr
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
   double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_rx, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
@@ -286,6 +288,7 @@ __device__ __forceinline__ double drow_dot(const double *__restrict__ r, int len
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_fold_fwd(Dev d) {
+  const unsigned long long t_in = d.prof ? wall_clock64() : 0;
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
@@ -294,11 +297,16 @@ __global__ __launch_bounds__(256) void k_fold_fwd(Dev d) {
   acc[0] = drow_dot<TPR>(d.f_rows + (size_t)row * d.ldf, d.M + row, d.wh, t);
   row_reduce<TPR, 1>(acc, lds);
   if (live && t == 0) d.ut[row] = di * (rxi + acc[0]);
+  if (d.prof && threadIdx.x == 0) {
+    d.prof[2 * blockIdx.x] = t_in;
+    d.prof[2 * blockIdx.x + 1] = wall_clock64();
+  }
 }
 
 template <int TPR_X, int TPR_C>
 __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
   __shared__ double lds[16];
+  const unsigned long long t_in = d.prof ? wall_clock64() : 0;
   const int n = d.n;
   constexpr int RPX = 256 / TPR_X, RPC = 256 / TPR_C;
   const int nbx = (n + RPX - 1) / RPX;
@@ -327,6 +335,10 @@ __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
       d.dx[row] = xn - xp;
       d.rx[row] = d.sigma * xn - qi;
     }
+    if (d.prof && threadIdx.x == 0) {
+      d.prof[2 * blockIdx.x] = t_in;
+      d.prof[2 * blockIdx.x + 1] = wall_clock64();
+    }
     return;
   }
   const int row_raw = (blockIdx.x - nbx) * RPC + threadIdx.x / TPR_C;
@@ -350,6 +362,10 @@ __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
     d.y[row] = yn;
     d.dy[row] = dy;
     d.wh[row] = zn - yn / rho;
+  }
+  if (d.prof && threadIdx.x == 0) {
+    d.prof[2 * blockIdx.x] = t_in;
+    d.prof[2 * blockIdx.x + 1] = wall_clock64();
   }
 }
 
@@ -1243,6 +1259,7 @@ struct miosqp_qp_engine {
   hipGraphExec_t x_full = nullptr, x_tail = nullptr;
   int chunk = 25, tail_iters = 0;
   int tpr_pv = 64, tpr_pc = 64, tpr_tail = 64, tpr_pb = 64, tpr_pr = 64;
+  int tpr_ff = 256, tpr_fx = 64, tpr_fc = 64;  // product-form kernels: forward rows, x rows, constraint rows
   // pinned staging: [l | u | x0 | y0] in, [x | y] out, ctrl
   double *h_in = nullptr, *h_out = nullptr;
   Ctrl *h_ctrl = nullptr;
@@ -1281,12 +1298,41 @@ int dupload(miosqp_qp_engine *e, const std::vector<T> &h, const T **p) {
   return 0;
 }
 
+void launch_fold_fwd(miosqp_qp_engine *e) {
+  const Dev &d = e->d;
+  DISPATCH_TPR(e->tpr_ff, k_fold_fwd, d.n, e->stream, d);
+}
+
+template <int TX>
+void launch_fold_bwd_c(miosqp_qp_engine *e) {
+  const Dev &d = e->d;
+  const int nbx = (d.n + 256 / TX - 1) / (256 / TX);
+#define FB(TC)                                                                                         \
+  hipLaunchKernelGGL((k_fold_bwd<TX, TC>), dim3(nbx + (d.M + 256 / TC - 1) / (256 / TC)), dim3(256), 0, \
+                     e->stream, d)
+  switch (e->tpr_fc) {
+    case 32: FB(32); break;
+    case 128: FB(128); break;
+    case 256: FB(256); break;
+    default: FB(64); break;
+  }
+#undef FB
+}
+
+void launch_fold_bwd(miosqp_qp_engine *e) {
+  switch (e->tpr_fx) {
+    case 16: launch_fold_bwd_c<16>(e); break;
+    case 32: launch_fold_bwd_c<32>(e); break;
+    case 128: launch_fold_bwd_c<128>(e); break;
+    default: launch_fold_bwd_c<64>(e); break;
+  }
+}
+
 void launch_iteration(miosqp_qp_engine *e) {
   const Dev &d = e->d;
   if (e->fold) {
-    hipLaunchKernelGGL(k_fold_fwd<256>, dim3(d.n), dim3(256), 0, e->stream, d);
-    const int nb = (d.n + 3) / 4 + (d.M + 3) / 4;
-    hipLaunchKernelGGL((k_fold_bwd<64, 64>), dim3(nb), dim3(256), 0, e->stream, d);
+    launch_fold_fwd(e);
+    launch_fold_bwd(e);
     return;
   }
   DISPATCH_TPR(e->tpr_pv, k_panel_fwd, d.n, e->stream, d);
@@ -1672,6 +1718,17 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       d.ldf = e->fo.ldf;
       d.ldn = e->fo.ldn;
       e->fold = true;
+      e->tpr_ff = pick_tpr(0.25 * (M + 0.5 * n));
+      e->tpr_fx = pick_tpr(0.5 * n);
+      e->tpr_fc = pick_tpr((double)n);
+      if (const char *ev = getenv("MIOSQP_FOLD_TPR")) {  // tuning hook: "fwd,x,c"
+        int a = 0, b = 0, c = 0;
+        if (sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3) {
+          e->tpr_ff = a;
+          e->tpr_fx = b;
+          e->tpr_fc = c;
+        }
+      }
       std::vector<double>().swap(e->fo.rows);
       std::vector<double>().swap(e->fo.GmT);
     }
@@ -1866,6 +1923,26 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
   return 0;
 }
 
+// debug: per-block (start, end) wall-clock stamps (100 MHz) of ONE launch of a product-form kernel
+int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
+                             int32_t *nblocks) {
+  if (!e || !out || !e->fold || which < 0 || which > 1) return MIOSQP_EARG;
+  unsigned long long *buf = nullptr;
+  HIPCHK(hipMalloc((void **)&buf, sizeof(unsigned long long) * 2 * 8192));
+  HIPCHK(hipMemset(buf, 0, sizeof(unsigned long long) * 2 * 8192));
+  for (int i = 0; i < 20; i++) launch_iteration(e);
+  Dev saved = e->d;
+  e->d.prof = buf;
+  if (which == 0) launch_fold_fwd(e); else launch_fold_bwd(e);
+  e->d = saved;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int nb = max_blocks < 8192 ? max_blocks : 8192;
+  HIPCHK(hipMemcpy(out, buf, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
+  if (nblocks) *nblocks = nb;
+  hipFree(buf);
+  return 0;
+}
+
 int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters, int64_t *node_iters,
                               int32_t reset) {
   if (!e) return MIOSQP_EARG;
@@ -1891,9 +1968,8 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, d);
   auto one = [&]() {
     if (e->fold && which < 4) {
-      if (which == 0) hipLaunchKernelGGL(k_fold_fwd<256>, dim3(d.n), dim3(256), 0, e->stream, d);
-      if (which == 1)
-        hipLaunchKernelGGL((k_fold_bwd<64, 64>), dim3((d.n + 3) / 4 + (d.M + 3) / 4), dim3(256), 0, e->stream, d);
+      if (which == 0) launch_fold_fwd(e);
+      if (which == 1) launch_fold_bwd(e);
       return;
     }
     if (e->fold && which >= 10 && which < 14) {

@@ -265,7 +265,7 @@ def _wave_of_nodes(oracle_mod, pr, count):
 
 @pytest.mark.parametrize("n,m,p,seed,count,fold", [(20, 40, 10, 1, 7, -1), (50, 100, 25, 2, 70, 0),
                                                     (50, 100, 25, 2, 70, 1), (130, 260, 65, 3, 130, -1),
-                                                    (37, 3, 5, 4, 9, 1)])
+                                                    (37, 3, 20, 4, 9, 1), (33, 2, 16, 6, 9, 0)])
 def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold):
     """solve_batch on a wave of real B&B leaves == solve_node on each == the oracle."""
     from miosqp_amd import qp
