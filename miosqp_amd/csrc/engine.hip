@@ -1718,7 +1718,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       d.ldf = e->fo.ldf;
       d.ldn = e->fo.ldn;
       e->fold = true;
-      e->tpr_ff = pick_tpr(0.25 * (M + 0.5 * n));
+      e->tpr_ff = pick_tpr(M + 0.5 * n);
       e->tpr_fx = pick_tpr(0.5 * n);
       e->tpr_fc = pick_tpr((double)n);
       if (const char *ev = getenv("MIOSQP_FOLD_TPR")) {  // tuning hook: "fwd,x,c"
