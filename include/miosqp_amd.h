@@ -61,7 +61,9 @@ typedef struct miosqp_qp_settings {
   int32_t max_batch;         /* capacity of miosqp_qp_solve_batch (>= 1) */
   int32_t fold;              /* -1 auto, 0 factor form L (4 kernels/iteration), 1 product form L^-1
                                 (2 kernels/iteration; auto picks it for panels denser than 30 %) */
-  int32_t reserved[5];
+  int32_t resident;          /* -1 auto, 0 off, 1 on: whole solve in ONE LDS-resident workgroup when the
+                                product-form factor and all iterates fit in 160 KB of LDS */
+  int32_t reserved[4];
 } miosqp_qp_settings;
 
 /* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus
@@ -144,7 +146,7 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
 
 /* sizes of the factor: out[0]=nnz(L) strict (panel + tail), out[1]=nnz panel, out[2]=tail order,
  * out[3]=algorithmic bytes per ADMM iteration (SURVEY.md sec. 8d formula), out[4..6] threads per
- * row of the panel/tail kernels, out[7]=1 when the product-form factor is in use */
+ * row of the panel/tail kernels, out[7] bit 0 = product-form factor in use, bit 1 = LDS-resident solver in use */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
 
 /* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's

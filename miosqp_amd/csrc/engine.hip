@@ -17,6 +17,7 @@
 // captured once in a hipGraph.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -62,7 +63,7 @@ struct Ctrl {
 // everything a kernel needs, passed by value
 struct Dev {
   int n, M, ld, n_int, m_orig;
-  double rho, sigma, alpha, eps_abs, eps_rel, eps_pinf, eps_dinf, c, cinv;
+  double rho, rho_inv, sigma, alpha, eps_abs, eps_rel, eps_pinf, eps_dinf, c, cinv;
   // panel by variable (n rows) / by constraint (M rows)
   const int *pv_ptr, *pv_idx;
   const double *pv_L, *pv_At;
@@ -104,14 +105,35 @@ struct Dev {
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
+// lane exchange inside a 16-lane row through DPP (no LDS crossbar): quad_perm xor 1 / xor 2, then
+// row_half_mirror and row_mirror, which act as xor 4 / xor 8 once the smaller groups are uniform
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// butterfly sum over aligned groups of W lanes (W a power of two), small strides first; fixed order
+template <int NV>
+__device__ __forceinline__ void group_sum(double (&v)[NV], int W) {
+#define GS_DPP(MIN, CTRL)                                                            \
+  if (W > MIN) {                                                                     \
+    _Pragma("unroll") for (int k = 0; k < NV; k++) v[k] += dpp_get<CTRL>(v[k]);      \
+  }
+#define GS_SHFL(MIN, OFF)                                                            \
+  if (W > MIN) {                                                                     \
+    _Pragma("unroll") for (int k = 0; k < NV; k++) v[k] += __shfl_xor(v[k], OFF, 64); \
+  }
+  GS_DPP(1, 0xB1) GS_DPP(2, 0x4E) GS_DPP(4, 0x141) GS_DPP(8, 0x140) GS_SHFL(16, 16) GS_SHFL(32, 32)
+#undef GS_DPP
+#undef GS_SHFL
+}
+
 template <int TPR, int NV>
 __device__ __forceinline__ void row_reduce(double (&v)[NV], double *lds) {
   constexpr int W = TPR < 64 ? TPR : 64;
-#pragma unroll
-  for (int off = W / 2; off > 0; off >>= 1) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) v[k] += __shfl_xor(v[k], off, 64);
-  }
+  group_sum<NV>(v, W);
   if constexpr (TPR > 64) {
     constexpr int WPR = TPR / 64;
     const int wave = threadIdx.x >> 6;
@@ -238,19 +260,19 @@ __global__ __launch_bounds__(256) void k_panel_bwd(Dev d) {
   acc[0] = prow_dot<TPR>(d.pc_idx, d.pc_L, d.pc_ptr[row], d.pc_ptr[row + 1], t, d.xt);
   row_reduce<TPR, 1>(acc, lds);
   if (live && t == 0) {
-    const double rho = d.rho, alpha = d.alpha;
+    const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
     const double zp = d.z[row], yp = d.y[row];
     const double nu = -rho * d.wh[row] - acc[0];
-    const double zt = zp + (nu - yp) / rho;
+    const double zt = zp + rinv * (nu - yp);
     const double zr = alpha * zt + (1.0 - alpha) * zp;
-    const double v = zr + yp / rho;
+    const double v = zr + rinv * yp;
     const double zn = fmin(fmax(v, d.l[row]), d.u[row]);
     const double dy = rho * (zr - zn);
     const double yn = yp + dy;
     d.z[row] = zn;
     d.y[row] = yn;
     d.dy[row] = dy;
-    d.wh[row] = zn - yn / rho;
+    d.wh[row] = zn - rinv * yn;
   }
 }
 
@@ -350,18 +372,18 @@ __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
   acc[0] = drow_dot<TPR_C>(d.f_GmT + (size_t)row * d.ldn, n, d.ut, t);
   row_reduce<TPR_C, 1>(acc, lds);
   if (live && t == 0) {
-    const double rho = d.rho, alpha = d.alpha;
+    const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
     const double nu = -rho * whj + acc[0];
-    const double zt = zp + (nu - yp) / rho;
+    const double zt = zp + rinv * (nu - yp);
     const double zr = alpha * zt + (1.0 - alpha) * zp;
-    const double v = zr + yp / rho;
+    const double v = zr + rinv * yp;
     const double zn = fmin(fmax(v, lj), uj);
     const double dy = rho * (zr - zn);
     const double yn = yp + dy;
     d.z[row] = zn;
     d.y[row] = yn;
     d.dy[row] = dy;
-    d.wh[row] = zn - yn / rho;
+    d.wh[row] = zn - rinv * yn;
   }
   if (d.prof && threadIdx.x == 0) {
     d.prof[2 * blockIdx.x] = t_in;
@@ -561,6 +583,275 @@ __global__ __launch_bounds__(256) void k_check_decide(Dev d, int iters_in_chunk)
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS-resident solver for small problems (BASELINE configs 1 and 4): ONE workgroup keeps the
+// product-form factor -- the n x (M+n) matrix [ -G | strict_lower(Linv) ] -- and every iterate
+// in LDS and runs the WHOLE ADMM loop, termination tests included, in a single launch; the two
+// all-to-all exchanges of an iteration become two __syncthreads.  The forward sweep reads the
+// matrix by rows, the backward sweep reads the SAME matrix by columns (x rows: Linv^T; constraint
+// rows: (-G)^T); the row stride is odd, so both directions are bank-conflict free.
+// ------------------------------------------------------------------------------------------
+constexpr int RES_THREADS = 512, RES_WAVES = RES_THREADS / 64;
+
+__host__ __device__ inline size_t resident_lds_doubles(int n, int M) {
+  const size_t ldr = (size_t)((M + n) | 1);
+  return (size_t)n * ldr + (size_t)(M + n) + 5 * (size_t)n + 6 * (size_t)M + 8 * (size_t)M + 4 * (size_t)n +
+         (size_t)NQ * RES_WAVES + NQ + 8;
+}
+
+template <int NV>
+__device__ __forceinline__ void group_reduce(double (&v)[NV], int tg) {
+  group_sum<NV>(v, tg);
+}
+
+// strided dot product over LDS operands with four independent chains (LDS latency, not
+// bandwidth, bounds a single-workgroup solver): sum_{k = k0, k0+st, ... < k1} a[k*sa] * b[k]
+__device__ __forceinline__ double lds_dot(const double *a, size_t sa, const double *b, int k0, int k1, int st) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = k0;
+  for (; k + 3 * st < k1; k += 4 * st) {
+    s0 = fma(a[(size_t)k * sa], b[k], s0);
+    s1 = fma(a[(size_t)(k + st) * sa], b[k + st], s1);
+    s2 = fma(a[(size_t)(k + 2 * st) * sa], b[k + 2 * st], s2);
+    s3 = fma(a[(size_t)(k + 3 * st) * sa], b[k + 3 * st], s3);
+  }
+  for (; k < k1; k += st) s0 = fma(a[(size_t)k * sa], b[k], s0);
+  return (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(RES_THREADS) void k_resident(Dev d, int max_iter, int check_every, int final_check,
+                                                          int TG1, int TG2) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = d.n, M = d.M, tid = threadIdx.x;
+  const int ldr = (M + n) | 1;
+  double *Rm = sm;
+  double *wr = Rm + (size_t)n * ldr;  // [wh (M) | rx (n)]
+  double *x = wr + M + n, *q = x + n, *d2 = q + n, *ut = d2 + n, *dx = ut + n;
+  double *z = dx + n, *y = z + M, *l = y + M, *u = l + M, *dy = u + M, *vp = dy + M;
+  double *smc = vp + M;       // 8 x M
+  double *snc = smc + 8 * M;  // 4 x n
+  double *part = snc + 4 * n; // NQ x waves
+  double *res = part + NQ * RES_WAVES;
+  const double rho = d.rho, rinv = d.rho_inv, sigma = d.sigma, alpha = d.alpha;
+  const unsigned long long clk0 = __builtin_readcyclecounter(), wall0 = wall_clock64();
+  // ---- load factor and state ----
+  for (int row = tid >> 6; row < n; row += RES_WAVES) {
+    const double *src = d.f_rows + (size_t)row * d.ldf;
+    for (int k = tid & 63; k < ldr; k += 64) Rm[(size_t)row * ldr + k] = k < M + row ? src[k] : 0.0;
+  }
+  for (int i = tid; i < n; i += RES_THREADS) {
+    const double xi = d.x[i], qi = d.q[i];
+    x[i] = xi;
+    q[i] = qi;
+    d2[i] = d.d2inv[i];
+    dx[i] = 0.0;
+    wr[M + i] = sigma * xi - qi;
+  }
+  for (int j = tid; j < M; j += RES_THREADS) {
+    const double zj = d.z[j], yj = d.y[j];
+    z[j] = zj;
+    y[j] = yj;
+    l[j] = d.l[j];
+    u[j] = d.u[j];
+    dy[j] = 0.0;
+    wr[j] = zj - rinv * yj;
+  }
+  __syncthreads();
+  const int NG1 = RES_THREADS / TG1, NG2 = RES_THREADS / TG2;
+  const int g1 = tid / TG1, t1 = tid % TG1, g2 = tid / TG2, t2 = tid % TG2;
+  int status = 0, it = 0;
+  // termination test on the LDS-resident iterates (sparse Abar / Pbar rows come from L2)
+  auto run_check = [&](int iter_now) -> int {
+    for (int j = g1; j < M; j += NG1) {
+      double acc[2] = {0.0, 0.0};
+      for (int k = d.pc_ptr[j] + t1; k < d.pc_ptr[j + 1]; k += TG1) {
+        const double a = d.pc_A[k];
+        const int c = d.pc_idx[k];
+        acc[0] = fma(a, x[c], acc[0]);
+        acc[1] = fma(a, dx[c], acc[1]);
+      }
+      group_reduce<2>(acc, TG1);
+      if (t1 == 0) {
+        const double ei = d.Einv[j], zz = z[j], lo = l[j], hi = u[j];
+        const bool uinf = hi > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
+        double v = dy[j];
+        if (uinf && linf) v = 0.0;
+        else if (uinf) v = fmin(v, 0.0);
+        else if (linf) v = fmax(v, 0.0);
+        const double adx = ei * acc[1];
+        smc[0 * M + j] = ei * (acc[0] - zz);
+        smc[1 * M + j] = ei * acc[0];
+        smc[2 * M + j] = ei * zz;
+        vp[j] = v;
+        smc[4 * M + j] = d.E[j] * v;
+        smc[5 * M + j] = hi * fmax(v, 0.0) + lo * fmin(v, 0.0);
+        smc[6 * M + j] = uinf ? -1.7e308 : adx;
+        smc[7 * M + j] = linf ? 1.7e308 : adx;
+      }
+    }
+    __syncthreads();
+    for (int i = g1; i < n; i += NG1) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = d.pb_ptr[i] + t1; k < d.pb_ptr[i + 1]; k += TG1) {
+        const double a = d.pb_val[k];
+        const int c = d.pb_idx[k];
+        acc[0] = fma(a, x[c], acc[0]);
+        acc[1] = fma(a, dx[c], acc[1]);
+      }
+      for (int k = d.pv_ptr[i] + t1; k < d.pv_ptr[i + 1]; k += TG1) {
+        const double a = d.pv_At[k];
+        const int c = d.pv_idx[k];
+        acc[2] = fma(a, y[c], acc[2]);
+        acc[3] = fma(a, vp[c], acc[3]);
+      }
+      group_reduce<4>(acc, TG1);
+      if (t1 == 0) {
+        snc[0 * n + i] = acc[0];
+        snc[1 * n + i] = d.Dinv[i] * acc[1];
+        snc[2 * n + i] = acc[2];
+        snc[3 * n + i] = d.Dinv[i] * acc[3];
+      }
+    }
+    __syncthreads();
+    double v[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; k++) v[k] = 0.0;
+    v[4] = -1.7e308;
+    v[5] = -1.7e308;
+    for (int j = tid; j < M; j += RES_THREADS) {
+      v[0] = fmax(v[0], fabs(smc[0 * M + j]));
+      v[1] = fmax(v[1], fabs(smc[1 * M + j]));
+      v[2] = fmax(v[2], fabs(smc[2 * M + j]));
+      v[3] = fmax(v[3], fabs(smc[4 * M + j]));
+      v[4] = fmax(v[4], smc[6 * M + j]);
+      v[5] = fmax(v[5], -smc[7 * M + j]);
+      v[13] += smc[5 * M + j];
+    }
+    for (int i = tid; i < n; i += RES_THREADS) {
+      const double di = d.Dinv[i], px = snc[0 * n + i], aty = snc[2 * n + i], qi = q[i], xi = x[i], dxi = dx[i];
+      v[6] = fmax(v[6], fabs(di * (px + qi + aty)));
+      v[7] = fmax(v[7], fabs(di * px));
+      v[8] = fmax(v[8], fabs(di * aty));
+      v[9] = fmax(v[9], fabs(di * qi));
+      v[10] = fmax(v[10], fabs(snc[1 * n + i]));
+      v[11] = fmax(v[11], fabs(snc[3 * n + i]));
+      v[12] = fmax(v[12], fabs(d.D[i] * dxi));
+      v[14] += qi * dxi;
+      v[15] += xi * px;
+      v[16] += qi * xi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        const double o = __shfl_xor(v[k], off, 64);
+        v[k] = k < NQ_MAX ? fmax(v[k], o) : v[k] + o;
+      }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < NQ; k++) part[k * RES_WAVES + (tid >> 6)] = v[k];
+    }
+    __syncthreads();
+    if (tid < NQ) {
+      double r = part[tid * RES_WAVES];
+      for (int w = 1; w < RES_WAVES; w++)
+        r = tid < NQ_MAX ? fmax(r, part[tid * RES_WAVES + w]) : r + part[tid * RES_WAVES + w];
+      res[tid] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      Norms nm{res[0], res[1], res[2], res[3], res[4], -res[5], res[6] * d.cinv, res[7], res[8], res[9], res[10],
+               res[11], res[12], res[13], res[14], res[15], res[16]};
+      double obj;
+      const int st = decide_status(d, nm, obj);
+      Ctrl *c = d.ctrl;
+      c->iter = iter_now;
+      c->pri_res = nm.pri;
+      c->dua_res = nm.dua;
+      c->obj_val = obj;
+      if (st) {
+        c->status = st;
+        c->done = 1;
+      }
+      res[NQ] = (double)st;
+    }
+    __syncthreads();
+    return (int)res[NQ];
+  };
+
+  bool checked = false;
+  for (it = 1; it <= max_iter; it++) {
+    // forward sweep: rows of L^-1
+    for (int row = g1; row < n; row += NG1) {
+      const double *r = Rm + (size_t)row * ldr;
+      double acc[1] = {lds_dot(r, 1, wr, t1, M + row, TG1)};
+      group_reduce<1>(acc, TG1);
+      if (t1 == 0) ut[row] = d2[row] * (wr[M + row] + acc[0]);
+    }
+    __syncthreads();
+    // backward sweep: columns of the same matrix, fused x / z / y update
+    for (int r = g2; r < n + M; r += NG2) {
+      double acc[1] = {0.0};
+      if (r < n) {
+        acc[0] = lds_dot(Rm + M + r, ldr, ut, r + 1 + t2, n, TG2);
+        group_reduce<1>(acc, TG2);
+        if (t2 == 0) {
+          const double xt = ut[r] + acc[0], xp = x[r];
+          const double xn = alpha * xt + (1.0 - alpha) * xp;
+          x[r] = xn;
+          dx[r] = xn - xp;
+          wr[M + r] = sigma * xn - q[r];
+        }
+      } else {
+        const int j = r - n;
+        acc[0] = lds_dot(Rm + j, ldr, ut, t2, n, TG2);
+        group_reduce<1>(acc, TG2);
+        if (t2 == 0) {
+          const double zp = z[j], yp = y[j];
+          const double nu = -rho * wr[j] + acc[0];
+          const double zt = zp + rinv * (nu - yp);
+          const double zr = alpha * zt + (1.0 - alpha) * zp;
+          const double v = zr + rinv * yp;
+          const double zn = fmin(fmax(v, l[j]), u[j]);
+          const double dyj = rho * (zr - zn);
+          const double yn = yp + dyj;
+          z[j] = zn;
+          y[j] = yn;
+          dy[j] = dyj;
+          wr[j] = zn - rinv * yn;
+        }
+      }
+    }
+    __syncthreads();
+    checked = false;
+    if (check_every > 0 && it % check_every == 0) {
+      checked = true;
+      status = run_check(it);
+      if (status) break;
+    }
+  }
+  if (it > max_iter) it = max_iter;
+  if (!status && !checked && final_check) status = run_check(it);
+  if (tid == 0 && !final_check) d.ctrl->iter = it;
+  if (tid == 0) {  // shader cycles and 100 MHz wall ticks of this launch (clock diagnosis)
+    d.ctrl->nrm_dy = (double)(__builtin_readcyclecounter() - clk0);
+    d.ctrl->nrm_dx = (double)(wall_clock64() - wall0);
+  }
+  // ---- write the iterates back ----
+  for (int i = tid; i < n; i += RES_THREADS) {
+    d.x[i] = x[i];
+    d.dx[i] = dx[i];
+    d.rx[i] = wr[M + i];
+  }
+  for (int j = tid; j < M; j += RES_THREADS) {
+    d.z[j] = z[j];
+    d.y[j] = y[j];
+    d.dy[j] = dy[j];
+    d.wh[j] = wr[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // per-solve prologue / epilogue
 // ------------------------------------------------------------------------------------------
 __global__ void k_reset_ctrl(Dev d) {
@@ -613,7 +904,7 @@ __global__ __launch_bounds__(256) void k_warm_z(Dev d) {
 
 __global__ void k_init_wh(Dev d) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < d.M) d.wh[j] = d.z[j] - d.y[j] / d.rho;
+  if (j < d.M) d.wh[j] = d.z[j] - d.rho_inv * d.y[j];
   if (j < d.n) d.rx[j] = d.sigma * d.x[j] - d.q[j];
 }
 
@@ -779,19 +1070,19 @@ __global__ __launch_bounds__(256) void kb_panel_bwd(Dev d) {
   const double acc = brow_dot(d.pc_idx, d.pc_L, d.pc_ptr[row], d.pc_ptr[row + 1], d.b_xt + b, Bs);
   if (d.c_done[b]) return;
   const size_t o = row * Bs + b;
-  const double rho = d.rho, alpha = d.alpha;
+  const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
   const double zp = d.b_z[o], yp = d.b_y[o];
   const double nu = -rho * d.b_wh[o] - acc;
-  const double zt = zp + (nu - yp) / rho;
+  const double zt = zp + rinv * (nu - yp);
   const double zr = alpha * zt + (1.0 - alpha) * zp;
-  const double v = zr + yp / rho;
+  const double v = zr + rinv * yp;
   const double zn = fmin(fmax(v, d.b_l[o]), d.b_u[o]);
   const double dy = rho * (zr - zn);
   const double yn = yp + dy;
   d.b_z[o] = zn;
   d.b_y[o] = yn;
   d.b_dy[o] = dy;
-  d.b_wh[o] = zn - yn / rho;
+  d.b_wh[o] = zn - rinv * yn;
 }
 
 __global__ __launch_bounds__(256) void kb_check_con(Dev d) {
@@ -969,7 +1260,7 @@ __global__ __launch_bounds__(512) void kbd_bwd(Dev d) {
   bd_dot(d.f_GmT, d.ldn, d.M, row0, 0, d.n, d.b_ut + b, Bs, lds, acc);
   if (w >= 4) return;
   if (d.c_done[b]) return;
-  const double rho = d.rho, alpha = d.alpha;
+  const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
 #pragma unroll
   for (int r = 0; r < BD_R; r++) {
     const int row = row0 + w * BD_R + r;
@@ -977,16 +1268,16 @@ __global__ __launch_bounds__(512) void kbd_bwd(Dev d) {
     const size_t o = row * Bs + b;
     const double zp = d.b_z[o], yp = d.b_y[o];
     const double nu = -rho * d.b_wh[o] + acc[r];
-    const double zt = zp + (nu - yp) / rho;
+    const double zt = zp + rinv * (nu - yp);
     const double zr = alpha * zt + (1.0 - alpha) * zp;
-    const double v = zr + yp / rho;
+    const double v = zr + rinv * yp;
     const double zn = fmin(fmax(v, d.b_l[o]), d.b_u[o]);
     const double dy = rho * (zr - zn);
     const double yn = yp + dy;
     d.b_z[o] = zn;
     d.b_y[o] = yn;
     d.b_dy[o] = dy;
-    d.b_wh[o] = zn - yn / rho;
+    d.b_wh[o] = zn - rinv * yn;
   }
 }
 
@@ -1131,7 +1422,7 @@ __global__ __launch_bounds__(256) void kb_warm_z(Dev d) {
   const double z = brow_dot(d.pc_idx, d.pc_A, d.pc_ptr[row], d.pc_ptr[row + 1], d.b_x + b, Bs);
   const size_t o = row * Bs + b;
   d.b_z[o] = z;
-  d.b_wh[o] = z - d.b_y[o] / d.rho;
+  d.b_wh[o] = z - d.rho_inv * d.b_y[o];
 }
 
 // unscale (or build the certificate) per column, then the integer clamp of node.py:131-136
@@ -1266,6 +1557,10 @@ struct miosqp_qp_engine {
   double *d_in = nullptr;
   bool have_int = false;
   bool fold = false;
+  bool res_pending = false;
+  bool resident = false;  // whole solve in one LDS-resident workgroup (small problems)
+  int res_tg1 = 64, res_tg2 = 64;
+  size_t res_lds = 0;
   miosqp::Folded fo;
   int64_t nnzA = 0, nnzPtriu = 0;
   // batched mode
@@ -1328,6 +1623,12 @@ void launch_fold_bwd(miosqp_qp_engine *e) {
   }
 }
 
+int launch_resident(miosqp_qp_engine *e, int max_iter, int check_every, int final_check) {
+  hipLaunchKernelGGL(k_resident, dim3(1), dim3(RES_THREADS), e->res_lds, e->stream, e->d, max_iter, check_every,
+                     final_check, e->res_tg1, e->res_tg2);
+  return 0;
+}
+
 void launch_iteration(miosqp_qp_engine *e) {
   const Dev &d = e->d;
   if (e->fold) {
@@ -1365,6 +1666,14 @@ double wall() {
 
 // runs the ADMM loop on the device until a status is decided or max_iter is reached
 int run_loop(miosqp_qp_engine *e) {
+  if (e->resident) {
+    HIPCHK(hipEventRecord(e->evc0, e->stream));
+    int rc = launch_resident(e, e->st.max_iter, e->st.check_termination, 1);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->evc1, e->stream));
+    e->res_pending = true;
+    return 0;
+  }
   const int nfull = e->st.max_iter / e->chunk;
   for (int k = 0; k < nfull; k++) {
     HIPCHK(hipEventRecord(e->evc0, e->stream));
@@ -1398,6 +1707,13 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
   memcpy(y_out, e->h_out + e->n, sizeof(double) * e->M);
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  if (e->res_pending) {
+    float lms = 0;
+    HIPCHK(hipEventElapsedTime(&lms, e->evc0, e->evc1));
+    e->loop_ms += lms;
+    e->loop_iters += e->h_ctrl->iter;
+    e->res_pending = false;
+  }
   info->status_val = e->h_ctrl->status;
   info->iter = e->h_ctrl->iter;
   info->obj_val = e->h_ctrl->obj_val;
@@ -1564,6 +1880,7 @@ int miosqp_qp_default_settings(miosqp_qp_settings *s) {
   s->device = -1;
   s->max_batch = 1;
   s->fold = -1;
+  s->resident = -1;
   return 0;
 }
 
@@ -1647,7 +1964,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   const miosqp::Factor &f = e->fa;
   Dev &d = e->d;
   d.n = n; d.M = M; d.ld = f.ld; d.n_int = 0; d.m_orig = M;
-  d.rho = s->rho; d.sigma = s->sigma; d.alpha = s->alpha; d.eps_abs = s->eps_abs; d.eps_rel = s->eps_rel;
+  d.rho = s->rho; d.rho_inv = 1.0 / s->rho; d.sigma = s->sigma; d.alpha = s->alpha; d.eps_abs = s->eps_abs; d.eps_rel = s->eps_rel;
   d.eps_pinf = s->eps_prim_inf; d.eps_dinf = s->eps_dual_inf; d.c = e->sc.c; d.cinv = e->sc.cinv;
 #define UP(vec, field)                                   \
   do {                                                   \
@@ -1709,7 +2026,8 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     const double dens = M > 0 ? (double)f.nnz_panel / ((double)n * M) : 0.0;
     const double fold_bytes = 8.0 * ((double)n * (M + n) + (double)M * n);
     int want = s->fold;
-    if (want < 0) want = (M > 0 && dens >= 0.30 && fold_bytes <= 4.0e9) ? 1 : 0;
+    const bool fits_lds = resident_lds_doubles(n, M) * sizeof(double) <= 150 * 1024;
+    if (want < 0) want = (M > 0 && ((dens >= 0.30 && fold_bytes <= 4.0e9) || (fits_lds && s->resident != 0))) ? 1 : 0;
     if (want && M > 0) {
       miosqp::build_folded(f, e->fo);
       int rc = dupload(e, e->fo.rows, &d.f_rows);
@@ -1721,6 +2039,25 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       e->tpr_ff = pick_tpr(M + 0.5 * n);
       e->tpr_fx = pick_tpr(0.5 * n);
       e->tpr_fc = pick_tpr((double)n);
+      {
+        const size_t need = resident_lds_doubles(n, M) * sizeof(double);
+        int wantr = s->resident;
+        if (wantr < 0) wantr = need <= 150 * 1024 ? 1 : 0;
+        if (wantr && need <= 160 * 1024) {
+          e->resident = true;
+          e->res_lds = need;
+          HIPCHK(hipFuncSetAttribute((const void *)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)need));
+          // lanes per row: as many as keep every row of a sweep in flight at once
+          auto pow2_floor = [](int v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
+          e->res_tg1 = std::min(64, std::max(1, pow2_floor(RES_THREADS / n)));
+          e->res_tg2 = std::min(64, std::max(1, pow2_floor(RES_THREADS / (n + M))));
+          if (const char *ev = getenv("MIOSQP_RES_TG")) {
+            int a1 = 0, b1 = 0;
+            if (sscanf(ev, "%d,%d", &a1, &b1) == 2) { e->res_tg1 = a1; e->res_tg2 = b1; }
+          }
+        }
+      }
       if (const char *ev = getenv("MIOSQP_FOLD_TPR")) {  // tuning hook: "fwd,x,c"
         int a = 0, b = 0, c = 0;
         if (sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3) {
@@ -1871,7 +2208,14 @@ int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z
   if (!e || k < 0) return MIOSQP_EARG;
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, e->d);
   hipLaunchKernelGGL(k_init_wh, dim3(((e->M > e->n ? e->M : e->n) + 255) / 256), dim3(256), 0, e->stream, e->d);
-  for (int i = 0; i < k; i++) launch_iteration(e);
+  if (e->resident) {
+    if (k > 0) {
+      int rc = launch_resident(e, k, 0, 0);
+      if (rc) return rc;
+    }
+  } else {
+    for (int i = 0; i < k; i++) launch_iteration(e);
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
   if (x) HIPCHK(hipMemcpy(x, e->d.x, sizeof(double) * e->n, hipMemcpyDeviceToHost));
   if (z) HIPCHK(hipMemcpy(z, e->d.z, sizeof(double) * e->M, hipMemcpyDeviceToHost));
@@ -1908,7 +2252,7 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[1] = e->fa.nnz_panel;
   out[2] = e->n;
   out[3] = (int64_t)b[4];
-  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = e->fold ? 1 : 0;
+  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0);
   return 0;
 }
 
@@ -1940,6 +2284,17 @@ int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, 
   HIPCHK(hipMemcpy(out, buf, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
   if (nblocks) *nblocks = nb;
   hipFree(buf);
+  return 0;
+}
+
+// debug: shader cycles and 100 MHz wall ticks recorded by the last LDS-resident launch
+int miosqp_qp_debug_clock(miosqp_qp_engine *e, double *cycles, double *ticks) {
+  if (!e) return MIOSQP_EARG;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  Ctrl c;
+  HIPCHK(hipMemcpy(&c, e->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+  *cycles = c.nrm_dy;
+  *ticks = c.nrm_dx;
   return 0;
 }
 

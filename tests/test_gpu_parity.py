@@ -327,16 +327,17 @@ def test_batched_search_finds_the_same_optimum():
     np.testing.assert_array_equal(out[0][2][ii], out[1][2][ii])
 
 
-@pytest.mark.parametrize("fold", [0, 1])
-def test_both_factor_forms_match_oracle(oracle_mod, fold):
-    """fold=0: factor form L (4 kernels per iteration); fold=1: product form L^-1 (2 kernels)."""
+@pytest.mark.parametrize("fold,resident", [(0, 0), (1, 0), (1, 1)])
+def test_both_factor_forms_match_oracle(oracle_mod, fold, resident):
+    """fold=0: factor form L (4 kernels per iteration); fold=1: product form L^-1 (2 kernels);
+    resident=1: the whole solve in one LDS-resident workgroup."""
     from miosqp_amd import qp
     pr = problems.random_miqp(60, 120, 30, seed=11)
     A, l, u = problems.extended(pr)
     g, o = qp.OSQP(), oracle_mod.OSQP()
-    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, **problems.QP_SETTINGS)
+    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, **problems.QP_SETTINGS)
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
-    assert g.factor_stats()["fold"] == bool(fold)
+    assert g.factor_stats()["fold"] == bool(fold) and g.factor_stats()["resident"] == bool(resident)
     rng = np.random.RandomState(3)
     x0, y0 = rng.randn(60), rng.randn(A.shape[0])
     for k in (1, 3, 40):
