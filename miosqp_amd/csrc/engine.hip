@@ -1139,17 +1139,20 @@ __global__ __launch_bounds__(256) void kb_check_var(Dev d) {
 // loads in flight during the FMAs), matrix entries are wave-uniform scalar loads, each LDS value
 // feeds both rows.  The two k halves are added in LDS in a fixed order.
 // ------------------------------------------------------------------------------------------
-constexpr int BD_KT = 16, BD_R = 2, BD_RG = 4, BD_ROWS = BD_R * BD_RG;  // 8 rows per workgroup
+constexpr int BD_KT = 16, BD_R = 2;
 
+// RG row groups x KS slices of the k range = RG*KS waves per workgroup, 2*RG rows per workgroup
+template <int RG, int KS>
 __device__ __forceinline__ void bd_dot(const double *__restrict__ A, int ld, int nrows, int row0, int kbeg,
                                        int kend, const double *__restrict__ V, size_t Bs, double *lds,
                                        double (&acc)[BD_R]) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int rg = w & 3, kh = w >> 2;
+  const int rg = w % RG, kh = w / RG;
+  constexpr int LPT = BD_KT / RG;  // tile rows staged per wave
   const int k0 = kbeg & ~(BD_KT - 1);
-  const int nt_half = ((kend - k0 + BD_KT - 1) / BD_KT + 1) / 2;
-  const int kstart = k0 + kh * nt_half * BD_KT;
+  const int nt_slice = ((kend - k0 + BD_KT - 1) / BD_KT + KS - 1) / KS;
+  const int kstart = k0 + kh * nt_slice * BD_KT;
   double *buf = lds + kh * (2 * BD_KT * 64);
   int ra = row0 + rg * BD_R, rb = ra + 1;
   ra = ra < nrows ? ra : nrows - 1;
@@ -1157,22 +1160,22 @@ __device__ __forceinline__ void bd_dot(const double *__restrict__ A, int ld, int
   const double *__restrict__ a0 = A + (size_t)ra * ld;
   const double *__restrict__ a1 = A + (size_t)rb * ld;
   acc[0] = acc[1] = 0.0;
-  double p[4];
+  double p[LPT];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int k = kstart + rg + 4 * i;
+  for (int i = 0; i < LPT; i++) {
+    const int k = kstart + rg + RG * i;
     p[i] = k < kend ? V[(size_t)k * Bs] : 0.0;
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) buf[(rg + 4 * i) * 64 + lane] = p[i];
+  for (int i = 0; i < LPT; i++) buf[(rg + RG * i) * 64 + lane] = p[i];
   __syncthreads();
-  for (int t = 0; t < nt_half; t++) {
+  for (int t = 0; t < nt_slice; t++) {
     const int kt = kstart + t * BD_KT;
-    const bool more = t + 1 < nt_half;
+    const bool more = t + 1 < nt_slice;
     if (more) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int k = kt + BD_KT + rg + 4 * i;
+      for (int i = 0; i < LPT; i++) {
+        const int k = kt + BD_KT + rg + RG * i;
         p[i] = k < kend ? V[(size_t)k * Bs] : 0.0;
       }
     }
@@ -1186,37 +1189,48 @@ __device__ __forceinline__ void bd_dot(const double *__restrict__ A, int ld, int
     if (more) {
       double *nxt = buf + ((t + 1) & 1) * (BD_KT * 64);
 #pragma unroll
-      for (int i = 0; i < 4; i++) nxt[(rg + 4 * i) * 64 + lane] = p[i];
+      for (int i = 0; i < LPT; i++) nxt[(rg + RG * i) * 64 + lane] = p[i];
     }
     __syncthreads();
   }
-  // add the second half of the k range (fixed order: first half + second half)
-  double *red = lds + 4 * BD_KT * 64;
-  if (kh == 1) {
-    red[(rg * BD_R + 0) * 64 + lane] = acc[0];
-    red[(rg * BD_R + 1) * 64 + lane] = acc[1];
+  // add the k slices in a fixed order: slice 0 + slice 1 + ...
+  double *red = lds + KS * 2 * BD_KT * 64;
+  if (kh > 0) {
+    red[((kh - 1) * RG * BD_R + rg * BD_R + 0) * 64 + lane] = acc[0];
+    red[((kh - 1) * RG * BD_R + rg * BD_R + 1) * 64 + lane] = acc[1];
   }
   __syncthreads();
   if (kh == 0) {
-    acc[0] += red[(rg * BD_R + 0) * 64 + lane];
-    acc[1] += red[(rg * BD_R + 1) * 64 + lane];
+#pragma unroll
+    for (int s = 1; s < KS; s++) {
+      acc[0] += red[((s - 1) * RG * BD_R + rg * BD_R + 0) * 64 + lane];
+      acc[1] += red[((s - 1) * RG * BD_R + rg * BD_R + 1) * 64 + lane];
+    }
   }
 }
 
+template <int RG, int KS>
+struct BdCfg {
+  static constexpr int ROWS = RG * BD_R, THREADS = RG * KS * 64;
+  static constexpr int LDS = KS * 2 * BD_KT * 64 + (KS - 1) * RG * BD_R * 64;
+};
+
 // ut = D22^-1 ( rx + [ -G | strict_lower(Linv) ] [wh ; rx] ), rows of L^-1
-__global__ __launch_bounds__(512) void kbd_fwd(Dev d) {
+template <int RG, int KS>
+__global__ __launch_bounds__(RG *KS * 64) void kbd_fwd(Dev d) {
   if (d.ctrl->done) return;
-  __shared__ double lds[4 * BD_KT * 64 + BD_ROWS * 64];
+  using C = BdCfg<RG, KS>;
+  __shared__ double lds[C::LDS];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const size_t Bs = (size_t)d.Bs;
   const int b = blockIdx.y * 64 + lane;
-  const int row0 = blockIdx.x * BD_ROWS;
-  int kend = d.M + row0 + BD_ROWS;
+  const int row0 = blockIdx.x * C::ROWS;
+  int kend = d.M + row0 + C::ROWS;
   if (kend > d.M + d.n) kend = d.M + d.n;
   double acc[BD_R];
-  bd_dot(d.f_rows, d.ldf, d.n, row0, 0, kend, d.b_wh + b, Bs, lds, acc);
-  if (w >= 4) return;
+  bd_dot<RG, KS>(d.f_rows, d.ldf, d.n, row0, 0, kend, d.b_wh + b, Bs, lds, acc);
+  if (w >= RG) return;
 #pragma unroll
   for (int r = 0; r < BD_R; r++) {
     const int row = row0 + w * BD_R + r;
@@ -1225,19 +1239,21 @@ __global__ __launch_bounds__(512) void kbd_fwd(Dev d) {
 }
 
 // rows of L^-T: blocks [0, nbx) the x rows (strict upper Linv^T), the rest the constraint rows (-G)^T
-__global__ __launch_bounds__(512) void kbd_bwd(Dev d) {
+template <int RG, int KS>
+__global__ __launch_bounds__(RG *KS * 64) void kbd_bwd(Dev d) {
   if (d.ctrl->done) return;
-  __shared__ double lds[4 * BD_KT * 64 + BD_ROWS * 64];
+  using C = BdCfg<RG, KS>;
+  __shared__ double lds[C::LDS];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const size_t Bs = (size_t)d.Bs;
   const int b = blockIdx.y * 64 + lane;
-  const int nbx = (d.n + BD_ROWS - 1) / BD_ROWS;
+  const int nbx = (d.n + C::ROWS - 1) / C::ROWS;
   double acc[BD_R];
   if ((int)blockIdx.x < nbx) {
-    const int row0 = blockIdx.x * BD_ROWS;
-    bd_dot(d.LinvT, d.ld, d.n, row0, row0 + 1, d.n, d.b_ut + b, Bs, lds, acc);
-    if (w >= 4) return;
+    const int row0 = blockIdx.x * C::ROWS;
+    bd_dot<RG, KS>(d.LinvT, d.ld, d.n, row0, row0 + 1, d.n, d.b_ut + b, Bs, lds, acc);
+    if (w >= RG) return;
     const bool frozen = d.c_done[b] != 0;
 #pragma unroll
     for (int r = 0; r < BD_R; r++) {
@@ -1256,9 +1272,9 @@ __global__ __launch_bounds__(512) void kbd_bwd(Dev d) {
     }
     return;
   }
-  const int row0 = (blockIdx.x - nbx) * BD_ROWS;
-  bd_dot(d.f_GmT, d.ldn, d.M, row0, 0, d.n, d.b_ut + b, Bs, lds, acc);
-  if (w >= 4) return;
+  const int row0 = (blockIdx.x - nbx) * C::ROWS;
+  bd_dot<RG, KS>(d.f_GmT, d.ldn, d.M, row0, 0, d.n, d.b_ut + b, Bs, lds, acc);
+  if (w >= RG) return;
   if (d.c_done[b]) return;
   const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
 #pragma unroll
@@ -1550,6 +1566,7 @@ struct miosqp_qp_engine {
   hipGraphExec_t x_full = nullptr, x_tail = nullptr;
   int chunk = 25, tail_iters = 0;
   int tpr_pv = 64, tpr_pc = 64, tpr_tail = 64, tpr_pb = 64, tpr_pr = 64;
+  int bd_cfg = 44;  // batched dense kernels: 10*row_groups + k_slices
   int tpr_ff = 256, tpr_fx = 64, tpr_fc = 64;  // product-form kernels: forward rows, x rows, constraint rows
   // pinned staging: [l | u | x0 | y0] in, [x | y] out, ctrl
   double *h_in = nullptr, *h_out = nullptr;
@@ -1727,12 +1744,31 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
 
 
 // ---- batched mode (host) -------------------------------------------------------------------
+// which: 0 forward sweep, 1 backward sweep; workgroup shape from e->bd_cfg (row groups x k slices)
+void launch_bd(miosqp_qp_engine *e, int ntiles, int which) {
+  const Dev &d = e->d;
+#define BD(RG, KS)                                                                                         \
+  do {                                                                                                     \
+    constexpr int R = BdCfg<RG, KS>::ROWS, T = BdCfg<RG, KS>::THREADS;                                      \
+    const int nbx = (d.n + R - 1) / R, nbc = (d.M + R - 1) / R;                                            \
+    if (which == 0) hipLaunchKernelGGL((kbd_fwd<RG, KS>), dim3(nbx, ntiles), dim3(T), 0, e->stream, d);      \
+    else hipLaunchKernelGGL((kbd_bwd<RG, KS>), dim3(nbx + nbc, ntiles), dim3(T), 0, e->stream, d);           \
+  } while (0)
+  switch (e->bd_cfg) {
+    case 24: BD(2, 4); break;
+    case 44: BD(4, 4); break;
+    case 22: BD(2, 2); break;
+    case 28: BD(2, 8); break;
+    default: BD(4, 2); break;
+  }
+#undef BD
+}
+
 void launch_iteration_b(miosqp_qp_engine *e, int ntiles) {
   const Dev &d = e->d;
   if (e->fold) {
-    const int nbx = (d.n + BD_ROWS - 1) / BD_ROWS, nbc = (d.M + BD_ROWS - 1) / BD_ROWS;
-    hipLaunchKernelGGL(kbd_fwd, dim3(nbx, ntiles), dim3(512), 0, e->stream, d);
-    hipLaunchKernelGGL(kbd_bwd, dim3(nbx + nbc, ntiles), dim3(512), 0, e->stream, d);
+    launch_bd(e, ntiles, 0);
+    launch_bd(e, ntiles, 1);
     return;
   }
   hipLaunchKernelGGL(kb_panel_fwd, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
@@ -2058,6 +2094,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           }
         }
       }
+      if (const char *ev = getenv("MIOSQP_BD_CFG")) e->bd_cfg = atoi(ev);
       if (const char *ev = getenv("MIOSQP_FOLD_TPR")) {  // tuning hook: "fwd,x,c"
         int a = 0, b = 0, c = 0;
         if (sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3) {
@@ -2328,9 +2365,8 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
       return;
     }
     if (e->fold && which >= 10 && which < 14) {
-      const int nbx = (d.n + BD_ROWS - 1) / BD_ROWS, nbc = (d.M + BD_ROWS - 1) / BD_ROWS;
-      if (which == 10) hipLaunchKernelGGL(kbd_fwd, dim3(nbx, ntiles), dim3(512), 0, e->stream, d);
-      if (which == 11) hipLaunchKernelGGL(kbd_bwd, dim3(nbx + nbc, ntiles), dim3(512), 0, e->stream, d);
+      if (which == 10) launch_bd(e, ntiles, 0);
+      if (which == 11) launch_bd(e, ntiles, 1);
       return;
     }
     switch (which) {
