@@ -77,6 +77,12 @@ typedef struct miosqp_qp_info {
   double dua_res;
   double device_time; /* seconds between HIP events around the device work of this call */
   double lower;       /* solve_node/solve_batch only: objective at the clamped x (node.py:143) */
+  /* node digest (after miosqp_qp_set_root; -1 / NaN otherwise): what bound_and_branch needs next */
+  int32_t int_inf;    /* number of integer variables off by more than eps_int_feas (workspace.py:245-264) */
+  int32_t nextvar;    /* position in i_idx of the most fractional one (workspace.py:205-230) */
+  double heur_viol;   /* worst violation of the root bounds by the rounded candidate, eps_abs slack
+                         included: <= 0 means satisfies_lin_constraints (workspace.py:232-243, 321-323) */
+  double heur_obj;    /* objective of the rounded candidate (workspace.py:324) */
 } miosqp_qp_info;
 
 typedef struct miosqp_qp_engine miosqp_qp_engine;
@@ -113,6 +119,13 @@ int miosqp_qp_solve(miosqp_qp_engine *e, double *x_out, double *y_out, miosqp_qp
  * i_idx: n_int variable indices.  Must be called before solve_node / solve_batch. */
 int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t *i_idx,
                                int32_t m_orig);
+
+/* Enables the node digest: the part of Workspace.bound_and_branch that only needs the node's x
+ * (/root/reference/miosqp/workspace.py:245-272, 321-324) is evaluated on the device at the end of
+ * solve_node.  l_root/u_root: the ROOT bounds data.l / data.u (M doubles); eps_int_feas from the
+ * B&B settings; eps_lin = qp_settings['eps_abs'].  Call again after MIOSQP.update_vectors. */
+int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *u_root,
+                       double eps_int_feas, double eps_lin);
 
 /* Whole body of Node.solve() in one call -- /root/reference/miosqp/node.py:96-143:
  * update(l,u) -> warm_start(x0,y0) -> solve -> x[i_idx] clamped into [l[-n_int:], u[-n_int:]]

@@ -25,7 +25,9 @@ class Settings(C.Structure):
 class Info(C.Structure):
     _fields_ = [("status_val", C.c_int32), ("iter", C.c_int32), ("run_time", C.c_double),
                 ("obj_val", C.c_double), ("pri_res", C.c_double), ("dua_res", C.c_double),
-                ("device_time", C.c_double), ("lower", C.c_double)]
+                ("device_time", C.c_double), ("lower", C.c_double),
+                ("int_inf", C.c_int32), ("nextvar", C.c_int32), ("heur_viol", C.c_double),
+                ("heur_obj", C.c_double)]
 
 
 # every symbol include/miosqp_amd.h declares: name -> (restype, argtypes)
@@ -39,6 +41,7 @@ SYMBOLS = {
     "miosqp_qp_warm_start": (C.c_int, [C.c_void_p, dp, dp]),
     "miosqp_qp_solve": (C.c_int, [C.c_void_p, dp, dp, C.POINTER(Info)]),
     "miosqp_qp_set_integer_rows": (C.c_int, [C.c_void_p, C.c_int32, ip, C.c_int32]),
+    "miosqp_qp_set_root": (C.c_int, [C.c_void_p, dp, dp, C.c_double, C.c_double]),
     "miosqp_qp_solve_node": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, C.POINTER(Info)]),
     "miosqp_qp_solve_batch": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp,
                                         C.POINTER(Info)]),

@@ -104,6 +104,7 @@ class Node(object):
         self.status = self._constant('OSQP_UNSOLVED')
         self.nextvar_idx = None
         self.constr_idx = None
+        self.digest = None  # filled by the device epilogue (miosqp_qp_set_root) when available
 
     def _absorb(self, status, num_iter, run_time, x, y, lower):
         self.status = status
@@ -120,6 +121,7 @@ class Node(object):
             # fused device path: bounds + warm start + ADMM + clamp + objective in one call
             r = self.solver.solve_node(self.l, self.u, self.x, self.y)
             self._absorb(r.status_val, r.iter, r.run_time, r.x, r.y, r.lower)
+            self.digest = getattr(r, 'digest', None)
             return
         self.solver.update(l=self.l, u=self.u)
         self.solver.warm_start(x=self.x, y=self.y)
@@ -157,6 +159,7 @@ class Workspace(object):
         self.solver.setup(data.P, data.q, data.A, data.l, data.u, **qp_settings)
         if hasattr(self.solver, 'set_integer_rows'):
             self.solver.set_integer_rows(data.i_idx, data.m)
+        self.push_root()
         self._reset_counters()
         self.first_run = 1
         self.leaves = [self._make_root()]
@@ -165,6 +168,15 @@ class Workspace(object):
         self.setup_time = 0.
         self.solve_time = 0.
         self.run_time = 0.
+
+    def push_root(self):
+        """Hands the root bounds and the two tolerances to the engine so that the x-only part of
+        bound_and_branch (integrality test, branching variable, rounding heuristic) is evaluated on
+        the device at the end of each node (settings['device_digest'] = False keeps it on the host)."""
+        if hasattr(self.solver, 'set_root') and self.settings.get('device_digest', True) \
+                and 'eps_abs' in self.qp_settings and self.data.n_int > 0:
+            self.solver.set_root(self.data.l, self.data.u, self.settings['eps_int_feas'],
+                                 self.qp_settings['eps_abs'])
 
     # -- bookkeeping ---------------------------------------------------------------------
     def _reset_counters(self):
@@ -292,6 +304,26 @@ class Workspace(object):
             return
         if leaf.lower > self.upper_glob:
             return
+        dg = leaf.digest
+        if dg is not None:
+            # same decisions from the device digest of this node's x
+            leaf.intinf = dg.int_inf
+            if dg.int_inf == 0:
+                leaf.frac_idx = []
+                self.x = leaf.x
+                self.upper_glob = leaf.lower
+                self.prune()
+                return
+            if dg.heur_feasible and dg.heur_obj < self.upper_glob:
+                self.upper_glob = dg.heur_obj
+                self.x = self.get_integer_solution(leaf.x)
+                self.prune()
+            leaf.constr_idx = self.data.m + dg.nextvar
+            leaf.nextvar_idx = self.data.i_idx[dg.nextvar]
+            self.add_left(leaf)
+            self.add_right(leaf)
+            self.lower_glob = min(lf.lower for lf in self.leaves)
+            return
         if self.is_int_feas(leaf.x, leaf):
             self.x = leaf.x
             self.upper_glob = leaf.lower
@@ -408,6 +440,7 @@ class MIOSQP(object):
         work.data.update_vectors(q, l, u)
         if q is not None:
             work.solver.update(q=q)
+        work.push_root()
         work.leaves = [work._make_root()]
         work._reset_counters()
         work.solve_time = 0.

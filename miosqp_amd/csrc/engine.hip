@@ -58,6 +58,9 @@ struct Ctrl {
   double pri_res, dua_res, obj_val, lower;
   double nrm_dy, nrm_dx;  // certificate normalisers
   double pad2[2];
+  // node digest (branching epilogue, workspace.py:245-272 on the device)
+  int int_inf, nextvar, pad4[2];
+  double heur_viol, heur_obj;
 };
 
 // everything a kernel needs, passed by value
@@ -90,6 +93,10 @@ struct Dev {
   const double *f_rows, *f_GmT;
   int ldf, ldn;
   double *rx;  // sigma x - q, kept right behind wh so that [wh | rx] is one contiguous vector
+  // node digest: rounded candidate (unscaled / scaled), root bounds, tolerances
+  double *xi, *xis, *root_l, *root_u;
+  double eps_int, eps_lin;
+  int digest;
   unsigned long long *prof;  // debug timeline (per-block start/end, 100 MHz wall clock) or nullptr
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
@@ -196,6 +203,7 @@ __device__ __forceinline__ void prow_dot2(const int *__restrict__ idx, const dou
 // ------------------------------------------------------------------------------------------
 template <int TPR>
 __global__ __launch_bounds__(256) void k_panel_fwd(Dev d) {
+  if (d.ctrl->done) return;  // chunk queued ahead of a decided test
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(256) void k_panel_fwd(Dev d) {
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_tail_fwd(Dev d) {
+  if (d.ctrl->done) return;  // chunk queued ahead of a decided test
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(256) void k_tail_fwd(Dev d) {
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_tail_bwd(Dev d) {
+  if (d.ctrl->done) return;  // chunk queued ahead of a decided test
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
@@ -253,6 +263,7 @@ __global__ __launch_bounds__(256) void k_tail_bwd(Dev d) {
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_panel_bwd(Dev d) {
+  if (d.ctrl->done) return;  // chunk queued ahead of a decided test
   ROW_SETUP(TPR)
   const bool live = row_raw < d.M;
   const int row = live ? row_raw : d.M - 1;
@@ -284,10 +295,10 @@ __global__ __launch_bounds__(256) void k_panel_bwd(Dev d) {
 // ------------------------------------------------------------------------------------------
 template <int TPR>
 __device__ __forceinline__ double drow_dot(const double *__restrict__ r, int len, const double *__restrict__ v,
-                                           int t) {
+                                           int t, int skip = 0) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const int len2 = len & ~1;
-  int j = 2 * t;
+  int j = 2 * t + skip;
   for (; j + 2 * TPR < len2; j += 4 * TPR) {
     const double2 a = *reinterpret_cast<const double2 *>(r + j);
     const double2 b = *reinterpret_cast<const double2 *>(v + j);
@@ -310,13 +321,22 @@ __device__ __forceinline__ double drow_dot(const double *__restrict__ r, int len
 
 template <int TPR>
 __global__ __launch_bounds__(256) void k_fold_fwd(Dev d) {
+  const int done = d.ctrl->done;  // tested below, after the first loads are in flight
   const unsigned long long t_in = d.prof ? wall_clock64() : 0;
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
   const double rxi = d.rx[row], di = d.d2inv[row];
+  const double *__restrict__ rr = d.f_rows + (size_t)row * d.ldf;
+  const int len = d.M + row;
+  double2 pa = make_double2(0.0, 0.0), pb = make_double2(0.0, 0.0);
+  if (2 * t < (len & ~1)) {
+    pa = *reinterpret_cast<const double2 *>(rr + 2 * t);
+    pb = *reinterpret_cast<const double2 *>(d.wh + 2 * t);
+  }
+  if (done) return;  // chunk queued ahead of a decided test: nothing to do
   double acc[1];
-  acc[0] = drow_dot<TPR>(d.f_rows + (size_t)row * d.ldf, d.M + row, d.wh, t);
+  acc[0] = fma(pa.x, pb.x, pa.y * pb.y) + drow_dot<TPR>(rr, len, d.wh, t, 2 * TPR);
   row_reduce<TPR, 1>(acc, lds);
   if (live && t == 0) d.ut[row] = di * (rxi + acc[0]);
   if (d.prof && threadIdx.x == 0) {
@@ -327,6 +347,7 @@ __global__ __launch_bounds__(256) void k_fold_fwd(Dev d) {
 
 template <int TPR_X, int TPR_C>
 __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
+  const int done = d.ctrl->done;  // tested below, after the first loads are in flight
   __shared__ double lds[16];
   const unsigned long long t_in = d.prof ? wall_clock64() : 0;
   const int n = d.n;
@@ -340,6 +361,7 @@ __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
     const double *__restrict__ Ur = d.LinvT + (size_t)row * d.ld;
     const double *__restrict__ u = d.ut;
     const double ui = u[row], xp = d.x[row], qi = d.q[row];
+    if (done) return;
     double a0 = 0.0, a1 = 0.0;
     int j = row + 1 + t;
     for (; j + TPR_X < n; j += 2 * TPR_X) {
@@ -368,8 +390,15 @@ __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
   const bool live = row_raw < d.M;
   const int row = live ? row_raw : d.M - 1;
   const double whj = d.wh[row], zp = d.z[row], yp = d.y[row], lj = d.l[row], uj = d.u[row];
+  const double *__restrict__ gr = d.f_GmT + (size_t)row * d.ldn;
+  double2 pa = make_double2(0.0, 0.0), pb = make_double2(0.0, 0.0);
+  if (2 * t < (n & ~1)) {
+    pa = *reinterpret_cast<const double2 *>(gr + 2 * t);
+    pb = *reinterpret_cast<const double2 *>(d.ut + 2 * t);
+  }
+  if (done) return;
   double acc[1];
-  acc[0] = drow_dot<TPR_C>(d.f_GmT + (size_t)row * d.ldn, n, d.ut, t);
+  acc[0] = fma(pa.x, pb.x, pa.y * pb.y) + drow_dot<TPR_C>(gr, n, d.ut, t, 2 * TPR_C);
   row_reduce<TPR_C, 1>(acc, lds);
   if (live && t == 0) {
     const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
@@ -938,12 +967,67 @@ __global__ __launch_bounds__(1024) void k_finish(Dev d, int node, int max_iter) 
         const int i = d.i_idx[k];
         d.out_x[i] = fmin(fmax(d.out_x[i], d.raw_l[d.m_orig + k]), d.raw_u[d.m_orig + k]);
       }
+      if (d.digest) {
+        // is_int_feas + pick_nextvar (workspace.py:245-264, 205-230) and the rounded candidate of
+        // get_integer_solution (workspace.py:266-272); np.round == rint (half to even)
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) d.xi[i] = d.out_x[i];
+        __syncthreads();
+        int cnt = 0, bestk = 0x7fffffff;
+        double best = -1.0;
+        for (int k = tid; k < d.n_int; k += 1024) {
+          const int i = d.i_idx[k];
+          const double v = d.out_x[i], r = rint(v), f = fabs(v - r);
+          d.xi[i] = r;
+          cnt += f > d.eps_int;
+          if (f > best) { best = f; bestk = k; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          const double ob = __shfl_xor(best, off, 64);
+          const int ok = __shfl_xor(bestk, off, 64);
+          cnt += __shfl_xor(cnt, off, 64);
+          if (ob > best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+        }
+        __shared__ double sb[16];
+        __shared__ int sk[16], sc[16];
+        if ((tid & 63) == 0) { sb[tid >> 6] = best; sk[tid >> 6] = bestk; sc[tid >> 6] = cnt; }
+        __syncthreads();
+        if (tid == 0) {
+          for (int w = 1; w < 16; w++) {
+            cnt += sc[w];
+            if (sb[w] > best || (sb[w] == best && sk[w] < bestk)) { best = sb[w]; bestk = sk[w]; }
+          }
+          c->int_inf = cnt;
+          c->nextvar = bestk == 0x7fffffff ? -1 : bestk;
+        }
+        for (int i = tid; i < n; i += 1024) d.xis[i] = d.Dinv[i] * d.xi[i];
+      }
     }
   }
   if (tid == 0) {
     c->status = st;
     c->done = 1;
+    if (!(node && d.digest && (st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED))) {
+      c->int_inf = -1;
+      c->nextvar = -1;
+    }
     (void)max_iter;
+  }
+}
+
+// rounding heuristic: rows of A against the rounded candidate, worst violation of the ROOT bounds
+// with the eps_abs slack of satisfies_lin_constraints (workspace.py:232-243)
+template <int TPR>
+__global__ __launch_bounds__(256) void k_heur_rows(Dev d) {
+  ROW_SETUP(TPR)
+  const bool live = row_raw < d.M;
+  const int row = live ? row_raw : d.M - 1;
+  double acc[1];
+  acc[0] = prow_dot<TPR>(d.pc_idx, d.pc_A, d.pc_ptr[row], d.pc_ptr[row + 1], t, d.xis);
+  row_reduce<TPR, 1>(acc, lds);
+  if (live && t == 0) {
+    const double z = d.Einv[row] * acc[0];
+    d.sm[row] = fmax(d.root_l[row] - d.eps_lin - z, z - d.root_u[row] - d.eps_lin);
   }
 }
 
@@ -953,20 +1037,33 @@ __global__ __launch_bounds__(256) void k_obj_rows(Dev d) {
   ROW_SETUP(TPR)
   const bool live = row_raw < d.n;
   const int row = live ? row_raw : d.n - 1;
-  double acc[1];
-  acc[0] = prow_dot<TPR>(d.pr_idx, d.pr_val, d.pr_ptr[row], d.pr_ptr[row + 1], t, d.out_x);
-  row_reduce<TPR, 1>(acc, lds);
-  if (live && t == 0) d.sn[row] = d.out_x[row] * (0.5 * acc[0] + d.qraw[row]);
+  double acc[2];
+  prow_dot2<TPR>(d.pr_idx, d.pr_val, d.pr_ptr[row], d.pr_ptr[row + 1], t, d.out_x, d.digest ? d.xi : d.out_x, acc[0],
+                 acc[1]);
+  row_reduce<TPR, 2>(acc, lds);
+  if (live && t == 0) {
+    d.sn[row] = d.out_x[row] * (0.5 * acc[0] + d.qraw[row]);
+    if (d.digest) d.sn[d.n + row] = d.xi[row] * (0.5 * acc[1] + d.qraw[row]);
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_obj_sum(Dev d) {
   __shared__ double lds[16];
-  double s = 0;
+  double s = 0, s2 = 0, vmax = -1.7e308;
   for (int i = threadIdx.x; i < d.n; i += 1024) s += d.sn[i];
   s = block_sum(s, lds);
+  if (d.digest) {
+    for (int i = threadIdx.x; i < d.n; i += 1024) s2 += d.sn[d.n + i];
+    for (int j = threadIdx.x; j < d.M; j += 1024) vmax = fmax(vmax, d.sm[j]);
+    s2 = block_sum(s2, lds);
+    vmax = block_max(vmax, lds);
+  }
   if (threadIdx.x == 0) {
     const int st = d.ctrl->status;
-    d.ctrl->lower = (st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED) ? s : __builtin_nan("");
+    const bool ok = st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED;
+    d.ctrl->lower = ok ? s : __builtin_nan("");
+    d.ctrl->heur_obj = ok && d.digest ? s2 : __builtin_nan("");
+    d.ctrl->heur_viol = ok && d.digest ? vmax : __builtin_nan("");
   }
 }
 
@@ -1574,7 +1671,9 @@ struct miosqp_qp_engine {
   double *d_in = nullptr;
   bool have_int = false;
   bool fold = false;
-  bool res_pending = false;
+  bool res_pending = false, loop_pending = false;
+  Ctrl *h_ctrl2 = nullptr;  // two pinned slots for the pipelined chunk loop
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   bool resident = false;  // whole solve in one LDS-resident workgroup (small problems)
   int res_tg1 = 64, res_tg2 = 64;
   size_t res_lds = 0;
@@ -1691,20 +1790,30 @@ int run_loop(miosqp_qp_engine *e) {
     e->res_pending = true;
     return 0;
   }
+  // One chunk is always queued AHEAD of the one whose verdict the host is waiting for, so the GPU
+  // never idles across the host round trip; every kernel of a chunk exits at once when the
+  // previous test already decided (ctrl->done).
   const int nfull = e->st.max_iter / e->chunk;
-  for (int k = 0; k < nfull; k++) {
-    HIPCHK(hipEventRecord(e->evc0, e->stream));
-    HIPCHK(hipGraphLaunch(e->x_full, e->stream));
-    HIPCHK(hipEventRecord(e->evc1, e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_ctrl, e->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, e->evc0, e->evc1));
-    e->loop_ms += ms;
-    e->loop_iters += e->chunk;
-    if (e->h_ctrl->done) return 0;
+  const int total = nfull + (e->tail_iters > 0 ? 1 : 0);
+  HIPCHK(hipEventRecord(e->evc0, e->stream));
+  auto enqueue = [&](int k) -> int {
+    HIPCHK(hipGraphLaunch(k < nfull ? e->x_full : e->x_tail, e->stream));
+    HIPCHK(hipMemcpyAsync(&e->h_ctrl2[k & 1], e->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(e->ev_chunk[k & 1], e->stream));
+    return 0;
+  };
+  int rc = enqueue(0);
+  if (rc) return rc;
+  for (int k = 0; k < total; k++) {
+    if (k + 1 < total) {
+      rc = enqueue(k + 1);
+      if (rc) return rc;
+    }
+    HIPCHK(hipEventSynchronize(e->ev_chunk[k & 1]));
+    if (e->h_ctrl2[k & 1].done) break;
   }
-  if (e->tail_iters > 0) HIPCHK(hipGraphLaunch(e->x_tail, e->stream));
+  HIPCHK(hipEventRecord(e->evc1, e->stream));
+  e->loop_pending = true;
   return 0;
 }
 
@@ -1713,6 +1822,7 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
   const Dev &d = e->d;
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, e->stream, d, node, e->st.max_iter);
   if (node) {
+    if (d.digest) DISPATCH_TPR(e->tpr_pc, k_heur_rows, d.M, e->stream, d);
     DISPATCH_TPR(e->tpr_pr, k_obj_rows, d.n, e->stream, d);
     hipLaunchKernelGGL(k_obj_sum, dim3(1), dim3(1024), 0, e->stream, d);
   }
@@ -1724,12 +1834,12 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
   memcpy(y_out, e->h_out + e->n, sizeof(double) * e->M);
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-  if (e->res_pending) {
+  if (e->res_pending || e->loop_pending) {
     float lms = 0;
     HIPCHK(hipEventElapsedTime(&lms, e->evc0, e->evc1));
     e->loop_ms += lms;
     e->loop_iters += e->h_ctrl->iter;
-    e->res_pending = false;
+    e->res_pending = e->loop_pending = false;
   }
   info->status_val = e->h_ctrl->status;
   info->iter = e->h_ctrl->iter;
@@ -1737,6 +1847,10 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
   info->pri_res = e->h_ctrl->pri_res;
   info->dua_res = e->h_ctrl->dua_res;
   info->lower = e->h_ctrl->lower;
+  info->int_inf = node ? e->h_ctrl->int_inf : -1;
+  info->nextvar = node ? e->h_ctrl->nextvar : -1;
+  info->heur_viol = e->h_ctrl->heur_viol;
+  info->heur_obj = e->h_ctrl->heur_obj;
   info->device_time = 1e-3 * ms;
   info->run_time = wall() - t0;
   return 0;
@@ -1884,6 +1998,8 @@ int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, co
     info[b].dua_res = e->hb_dbl[B + b];
     info[b].obj_val = e->hb_dbl[2 * B + b];
     info[b].lower = e->hb_dbl[3 * B + b];
+    info[b].int_inf = info[b].nextvar = -1;
+    info[b].heur_viol = info[b].heur_obj = __builtin_nan("");
     info[b].run_time = wall_s / B;  // the wave's wall time, shared equally
     info[b].device_time = 1e-3 * ms / B;
   }
@@ -1941,6 +2057,9 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->h_in) hipHostFree(e->h_in);
   if (e->h_out) hipHostFree(e->h_out);
   if (e->h_ctrl) hipHostFree(e->h_ctrl);
+  if (e->h_ctrl2) hipHostFree(e->h_ctrl2);
+  if (e->ev_chunk[0]) hipEventDestroy(e->ev_chunk[0]);
+  if (e->ev_chunk[1]) hipEventDestroy(e->ev_chunk[1]);
   if (e->hb_in) hipHostFree(e->hb_in);
   if (e->hb_out) hipHostFree(e->hb_out);
   if (e->hb_int) hipHostFree(e->hb_int);
@@ -2022,6 +2141,8 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   AL(q, n); AL(qraw, n); AL(l, M); AL(u, M); AL(x, n); AL(z, M); AL(y, M); AL(wh, (size_t)M + n); AL(cv, n); AL(ut, n);
   AL(xt, n); AL(dx, n); AL(dy, M); AL(sm, 8 * (size_t)M); AL(sn, 10 * (size_t)n);
   d.rx = d.wh + M;
+  AL(xi, n); AL(xis, n); AL(root_l, M); AL(root_u, M);
+  d.digest = 0;
   AL(ctrl, 1);
   // staging block: raw_l | raw_u | raw_x | raw_y contiguous, out_x | out_y contiguous
   AL(raw_l, 2 * (size_t)M + n + M);
@@ -2043,6 +2164,9 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   HIPCHK(hipHostMalloc((void **)&e->h_in, sizeof(double) * (2 * (size_t)M + n + M + 1), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->h_out, sizeof(double) * ((size_t)n + M + 1), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->h_ctrl, sizeof(Ctrl), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&e->h_ctrl2, 2 * sizeof(Ctrl), hipHostMallocDefault));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_chunk[0], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_chunk[1], hipEventDisableTiming));
   // scaled q, raw q, scaled bounds
   HIPCHK(hipMemcpy(d.q, e->sc.q.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.qraw, q, sizeof(double) * n, hipMemcpyHostToDevice));
@@ -2187,6 +2311,23 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
   e->d.m_orig = m_orig;
   e->have_int = true;
   // the captured graphs hold Dev by value but never read n_int / m_orig / i_idx contents
+  return 0;
+}
+
+int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *u_root, double eps_int_feas,
+                       double eps_lin) {
+  if (!e || !l_root || !u_root || !e->have_int) {
+    g_err = "set_root: call miosqp_qp_set_integer_rows first";
+    return MIOSQP_EARG;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->M > 0) {
+    HIPCHK(hipMemcpy(e->d.root_l, l_root, sizeof(double) * e->M, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d.root_u, u_root, sizeof(double) * e->M, hipMemcpyHostToDevice));
+  }
+  e->d.eps_int = eps_int_feas;
+  e->d.eps_lin = eps_lin;
+  e->d.digest = 1;
   return 0;
 }
 

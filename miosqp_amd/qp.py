@@ -113,6 +113,12 @@ class OSQP(object):
         _check(self._lib.miosqp_qp_set_integer_rows(self._h, len(ii), _lib.as_i(ii), int(m_orig)),
                "set_integer_rows")
 
+    def set_root(self, l_root, u_root, eps_int_feas, eps_lin):
+        """Enable the on-device node digest (see miosqp_qp_set_root)."""
+        l_root, u_root = _f64(l_root, self.m, "l_root"), _f64(u_root, self.m, "u_root")
+        _check(self._lib.miosqp_qp_set_root(self._h, _lib.as_d(l_root), _lib.as_d(u_root),
+                                            float(eps_int_feas), float(eps_lin)), "set_root")
+
     # -- the reference's four calls ------------------------------------------------------------
     def update(self, q=None, l=None, u=None):
         if q is not None:
@@ -150,8 +156,12 @@ class OSQP(object):
         if rc == 1:
             raise ValueError("Lower bound must be lower than or equal to upper bound")
         lower = None if np.isnan(info.lower) else info.lower
+        digest = None
+        if info.int_inf >= 0:
+            digest = types.SimpleNamespace(int_inf=info.int_inf, nextvar=info.nextvar,
+                                           heur_feasible=info.heur_viol <= 0.0, heur_obj=info.heur_obj)
         return types.SimpleNamespace(x=x, y=y, status_val=info.status_val, iter=info.iter,
-                                     run_time=info.run_time, lower=lower, info=info)
+                                     run_time=info.run_time, lower=lower, info=info, digest=digest)
 
     def solve_batch(self, l, u, x0, y0):
         """B independent nodes sharing the factor; arrays are [B, .]."""

@@ -360,3 +360,30 @@ def test_both_factor_forms_match_oracle(oracle_mod, fold, resident):
     rg, ro = g.solve(), o.solve()
     assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
     assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL
+
+
+@pytest.mark.parametrize("n,m,p,seed", [(30, 150, 15, 4), (50, 100, 10, 0), (60, 20, 30, 9)])
+def test_device_digest_equals_host_logic(n, m, p, seed):
+    """The on-device branching epilogue (integrality test, branching variable, rounding heuristic:
+    workspace.py:245-272, 321-324) takes the same decisions as the host numpy code."""
+    from miosqp_amd import bnb
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    out = []
+    for dev in (False, True):
+        st = dict(problems.BNB_SETTINGS, device_digest=dev)
+        model = bnb.MIOSQP()
+        model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
+                    dict(problems.QP_SETTINGS))
+        rows = []
+        res = model.solve(observer=lambda w, lf: rows.append(
+            (lf.depth, lf.status, lf.num_iter, int(lf.intinf) if lf.intinf is not None else -1,
+             -1 if lf.constr_idx is None else int(lf.constr_idx), len(w.leaves), w.upper_glob, lf.lower)))
+        assert (rows[0][3] >= 0) and (model.work.leaves == [])
+        out.append((res.status, res.upper_glob, np.array(res.x), rows))
+    assert out[0][0] == out[1][0]
+    assert len(out[0][3]) == len(out[1][3])
+    for a, b in zip(out[0][3], out[1][3]):
+        assert a[:6] == b[:6]
+        assert abs(a[6] - b[6]) <= 1e-9 * max(1.0, abs(a[6])) or (np.isinf(a[6]) and np.isinf(b[6]))
+    assert abs(out[0][1] - out[1][1]) <= 1e-9 * max(1.0, abs(out[0][1]))
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=0, atol=1e-9)
