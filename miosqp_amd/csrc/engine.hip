@@ -362,14 +362,9 @@ __global__ __launch_bounds__(256) void k_fold_bwd(Dev d) {
     const double *__restrict__ u = d.ut;
     const double ui = u[row], xp = d.x[row], qi = d.q[row];
     if (done) return;
-    double a0 = 0.0, a1 = 0.0;
-    int j = row + 1 + t;
-    for (; j + TPR_X < n; j += 2 * TPR_X) {
-      a0 = fma(Ur[j], u[j], a0);
-      a1 = fma(Ur[j + TPR_X], u[j + TPR_X], a1);
-    }
-    if (j < n) a0 = fma(Ur[j], u[j], a0);
-    double acc[1] = {a0 + a1};
+    // entries on and below the diagonal are stored zeros, so start at the even column <= row + 1
+    const int j0 = (row + 1) & ~1;
+    double acc[1] = {drow_dot<TPR_X>(Ur + j0, n - j0, u + j0, t)};
     row_reduce<TPR_X, 1>(acc, lds);
     if (live && t == 0) {
       const double xt = ui + acc[0];
