@@ -97,6 +97,7 @@ struct Dev {
   double *xi, *xis, *root_l, *root_u;
   double eps_int, eps_lin;
   int digest;
+  int bm_ablate;  // debug: 1 = no operand loads, 2 = no matrix-core instructions
   unsigned long long *prof;  // debug timeline (per-block start/end, 100 MHz wall clock) or nullptr
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
@@ -1389,6 +1390,164 @@ __global__ __launch_bounds__(RG *KS * 64) void kbd_bwd(Dev d) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// batched mode, product-form factor, fp64 matrix cores.  With 256 right-hand sides the sweeps are
+// dense fp64 GEMMs (500 x 1750 x 256 for config 2); v_mfma_f64_16x16x4_f64 has the vector-FMA peak
+// but needs 1/8 of the operand traffic and no wave-uniform operand at all (the scalar cache is what
+// limits the kbd_* kernels).  One workgroup = KS waves sharing ONE 16 x 32 output tile: wave w takes
+// the 16-deep k chunks w, w+KS, ...; partial tiles are added in LDS in wave order (fixed order).
+// Fragment layout (MI355X_MICROARCH / cdna_hip_programming sec. 3): A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15], C/D row = (l>>4) + 4*reg, col = l&15.  Within a 16-deep chunk MFMA step s
+// covers k = k0 + 4*(l>>4) + s, so each lane reads its four A values as one 32-byte segment.
+// ------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int BM_KS = 8, BM_NT = 2, BM_COLS = 16 * BM_NT;
+
+__device__ __forceinline__ void bm_tile(const double *__restrict__ A, int ld, int nrows, int row0, int kbeg,
+                                        int kend, const double *__restrict__ V, size_t Bs, double4_t (&acc)[BM_NT],
+                                        int abl = 0) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r = lane & 15, j = lane >> 4;
+  int row = row0 + r;
+  row = row < nrows ? row : nrows - 1;
+  const double *__restrict__ ar = A + (size_t)row * ld + 4 * j;
+  const double *__restrict__ vr = V + r;
+#pragma unroll
+  for (int t = 0; t < BM_NT; t++) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int k0 = kbeg & ~15;
+  // software pipeline: operands of chunk c+1 are in flight while chunk c feeds the matrix core
+  double a[4], b[BM_NT][4], an[4], bn[BM_NT][4];
+  auto fetch = [&](int kc, double (&pa)[4], double (&pb)[BM_NT][4]) {
+    if (abl == 1) {  // debug ablation: no operand traffic
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        pa[s] = 1.0 + kc;
+#pragma unroll
+        for (int t = 0; t < BM_NT; t++) pb[t][s] = 2.0 + s;
+      }
+      return;
+    }
+    const double2 a01 = *reinterpret_cast<const double2 *>(ar + kc);
+    const double2 a23 = *reinterpret_cast<const double2 *>(ar + kc + 2);
+    pa[0] = a01.x; pa[1] = a01.y; pa[2] = a23.x; pa[3] = a23.y;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int k = kc + 4 * j + s;
+      const bool in = k < kend;
+#pragma unroll
+      for (int t = 0; t < BM_NT; t++) pb[t][s] = in ? vr[(size_t)k * Bs + 16 * t] : 0.0;
+    }
+  };
+  int kc = k0 + 16 * w;
+  if (kc < kend) fetch(kc, a, b);
+  for (; kc < kend; kc += 16 * BM_KS) {
+    const int kn = kc + 16 * BM_KS;
+    if (kn < kend) fetch(kn, an, bn);
+    if (abl == 2) {  // debug ablation: no matrix-core work
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int t = 0; t < BM_NT; t++) acc[t][0] += a[s] + b[t][s];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int t = 0; t < BM_NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[t][s], acc[t], 0, 0, 0);
+      }
+    }
+    if (kn < kend) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        a[s] = an[s];
+#pragma unroll
+        for (int t = 0; t < BM_NT; t++) b[t][s] = bn[t][s];
+      }
+    }
+  }
+}
+
+// adds the KS partial tiles in wave order; thread e < 512 ends up with output element e:
+// tile t = e / 256, reg = (e % 256) / 64, lane' = e % 64 -> row (lane'>>4) + 4*reg, col 16 t + (lane'&15)
+__device__ __forceinline__ double bm_reduce(const double4_t (&acc)[BM_NT], double *lds) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < BM_NT; t++) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) lds[((w * BM_NT + t) * 4 + g) * 64 + lane] = acc[t][g];
+  }
+  __syncthreads();
+  const int e = threadIdx.x;  // BM_KS * 64 == BM_NT * 256 threads
+  double s = lds[e];
+#pragma unroll
+  for (int ww = 1; ww < BM_KS; ww++) s += lds[ww * (BM_NT * 256) + e];
+  return s;
+}
+
+__global__ __launch_bounds__(BM_KS * 64) void kbm_fwd(Dev d) {
+  if (d.ctrl->done) return;
+  __shared__ double lds[BM_KS * BM_NT * 256];
+  const size_t Bs = (size_t)d.Bs;
+  const int row0 = blockIdx.x * 16, col0 = blockIdx.y * BM_COLS;
+  int kend = d.M + row0 + 16;
+  if (kend > d.M + d.n) kend = d.M + d.n;
+  double4_t acc[BM_NT];
+  bm_tile(d.f_rows, d.ldf, d.n, row0, 0, kend, d.b_wh + col0, Bs, acc, d.bm_ablate);
+  const double s = bm_reduce(acc, lds);
+  const int e = threadIdx.x, t = e >> 8, g = (e & 255) >> 6, ll = e & 63;
+  const int row = row0 + (ll >> 4) + 4 * g, b = col0 + 16 * t + (ll & 15);
+  if (row < d.n) d.b_ut[row * Bs + b] = d.d2inv[row] * (d.b_rx[row * Bs + b] + s);
+}
+
+__global__ __launch_bounds__(BM_KS * 64) void kbm_bwd(Dev d) {
+  if (d.ctrl->done) return;
+  __shared__ double lds[BM_KS * BM_NT * 256];
+  const size_t Bs = (size_t)d.Bs;
+  const int col0 = blockIdx.y * BM_COLS;
+  const int nbx = (d.n + 15) / 16;
+  const int e = threadIdx.x, t = e >> 8, g = (e & 255) >> 6, ll = e & 63;
+  const int b = col0 + 16 * t + (ll & 15);
+  double4_t acc[BM_NT];
+  if ((int)blockIdx.x < nbx) {
+    const int row0 = blockIdx.x * 16;
+    bm_tile(d.LinvT, d.ld, d.n, row0, row0 + 1, d.n, d.b_ut + col0, Bs, acc);
+    const double s = bm_reduce(acc, lds);
+    const int row = row0 + (ll >> 4) + 4 * g;
+    if (row >= d.n) return;
+    const size_t o = row * Bs + b;
+    const double xt = d.b_ut[o] + s;
+    d.b_xt[o] = xt;
+    if (!d.c_done[b]) {
+      const double xp = d.b_x[o];
+      const double xn = d.alpha * xt + (1.0 - d.alpha) * xp;
+      d.b_x[o] = xn;
+      d.b_dx[o] = xn - xp;
+      d.b_rx[o] = d.sigma * xn - d.q[row];
+    }
+    return;
+  }
+  const int row0 = (blockIdx.x - nbx) * 16;
+  bm_tile(d.f_GmT, d.ldn, d.M, row0, 0, d.n, d.b_ut + col0, Bs, acc);
+  const double s = bm_reduce(acc, lds);
+  const int row = row0 + (ll >> 4) + 4 * g;
+  if (row >= d.M || d.c_done[b]) return;
+  const size_t o = row * Bs + b;
+  const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
+  const double zp = d.b_z[o], yp = d.b_y[o];
+  const double nu = -rho * d.b_wh[o] + s;
+  const double zt = zp + rinv * (nu - yp);
+  const double zr = alpha * zt + (1.0 - alpha) * zp;
+  const double v = zr + rinv * yp;
+  const double zn = fmin(fmax(v, d.b_l[o]), d.b_u[o]);
+  const double dy = rho * (zr - zn);
+  const double yn = yp + dy;
+  d.b_z[o] = zn;
+  d.b_y[o] = yn;
+  d.b_dy[o] = dy;
+  d.b_wh[o] = zn - rinv * yn;
+}
+
 // column-wise reductions: 1024 threads = 64 columns x 16 row groups; fixed order
 #define COLRED(name, OP, init)                                                          \
   __device__ __forceinline__ double name(double v, double *lds, int bl, int rg) {       \
@@ -1403,63 +1562,63 @@ __device__ __forceinline__ double op_add(double a, double b) { return a + b; }
 COLRED(colred_max, fmax, 0)
 COLRED(colred_sum, op_add, 0)
 
-__global__ __launch_bounds__(1024) void kb_check_decide(Dev d) {
+// 256 threads = 64 columns x 4 row groups; all 17 quantities meet in LDS in ONE pass
+__global__ __launch_bounds__(256) void kb_check_decide(Dev d) {
   if (d.ctrl->done) return;
-  __shared__ double lds[16 * 64];
+  __shared__ double part[NQ][4][64];
   const int n = d.n, M = d.M, tid = threadIdx.x, bl = tid & 63, rg = tid >> 6;
   const int b = blockIdx.x * 64 + bl;
   const size_t Bs = (size_t)d.Bs, MB = (size_t)M * Bs, NB = (size_t)n * Bs;
-  Norms v{0, 0, 0, 0, -1.7e308, 1.7e308, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int j = rg; j < M; j += 16) {
+  double v[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = 0.0;
+  v[4] = -1.7e308;
+  v[5] = -1.7e308;
+  for (int j = rg; j < M; j += 4) {
     const size_t o = j * Bs + b;
-    v.pri = fmax(v.pri, fabs(d.b_sm[0 * MB + o]));
-    v.nAx = fmax(v.nAx, fabs(d.b_sm[1 * MB + o]));
-    v.nz = fmax(v.nz, fabs(d.b_sm[2 * MB + o]));
-    v.nEv = fmax(v.nEv, fabs(d.b_sm[4 * MB + o]));
-    v.lhs += d.b_sm[5 * MB + o];
-    v.amax_u = fmax(v.amax_u, d.b_sm[6 * MB + o]);
-    v.amin_l = fmin(v.amin_l, d.b_sm[7 * MB + o]);
+    v[0] = fmax(v[0], fabs(d.b_sm[0 * MB + o]));
+    v[1] = fmax(v[1], fabs(d.b_sm[1 * MB + o]));
+    v[2] = fmax(v[2], fabs(d.b_sm[2 * MB + o]));
+    v[3] = fmax(v[3], fabs(d.b_sm[4 * MB + o]));
+    v[4] = fmax(v[4], d.b_sm[6 * MB + o]);
+    v[5] = fmax(v[5], -d.b_sm[7 * MB + o]);
+    v[13] += d.b_sm[5 * MB + o];
   }
-  for (int i = rg; i < n; i += 16) {
+  for (int i = rg; i < n; i += 4) {
     const size_t o = i * Bs + b;
     const double di = d.Dinv[i], px = d.b_sn[0 * NB + o], aty = d.b_sn[2 * NB + o], q = d.q[i], x = d.b_x[o],
                  dx = d.b_dx[o];
-    v.dua = fmax(v.dua, fabs(di * (px + q + aty)));
-    v.nPx = fmax(v.nPx, fabs(di * px));
-    v.nAty = fmax(v.nAty, fabs(di * aty));
-    v.nq = fmax(v.nq, fabs(di * q));
-    v.nPdx = fmax(v.nPdx, fabs(d.b_sn[1 * NB + o]));
-    v.nAtv = fmax(v.nAtv, fabs(d.b_sn[3 * NB + o]));
-    v.ndx = fmax(v.ndx, fabs(d.D[i] * dx));
-    v.qdx += q * dx;
-    v.xPx += x * px;
-    v.qx += q * x;
+    v[6] = fmax(v[6], fabs(di * (px + q + aty)));
+    v[7] = fmax(v[7], fabs(di * px));
+    v[8] = fmax(v[8], fabs(di * aty));
+    v[9] = fmax(v[9], fabs(di * q));
+    v[10] = fmax(v[10], fabs(d.b_sn[1 * NB + o]));
+    v[11] = fmax(v[11], fabs(d.b_sn[3 * NB + o]));
+    v[12] = fmax(v[12], fabs(d.D[i] * dx));
+    v[14] += q * dx;
+    v[15] += x * px;
+    v[16] += q * x;
   }
-  v.pri = colred_max(v.pri, lds, bl, rg);
-  v.nAx = colred_max(v.nAx, lds, bl, rg);
-  v.nz = colred_max(v.nz, lds, bl, rg);
-  v.nEv = colred_max(v.nEv, lds, bl, rg);
-  v.lhs = colred_sum(v.lhs, lds, bl, rg);
-  v.amax_u = colred_max(v.amax_u, lds, bl, rg);
-  v.amin_l = -colred_max(-v.amin_l, lds, bl, rg);
-  v.dua = colred_max(v.dua, lds, bl, rg) * d.cinv;
-  v.nPx = colred_max(v.nPx, lds, bl, rg);
-  v.nAty = colred_max(v.nAty, lds, bl, rg);
-  v.nq = colred_max(v.nq, lds, bl, rg);
-  v.nPdx = colred_max(v.nPdx, lds, bl, rg);
-  v.nAtv = colred_max(v.nAtv, lds, bl, rg);
-  v.ndx = colred_max(v.ndx, lds, bl, rg);
-  v.qdx = colred_sum(v.qdx, lds, bl, rg);
-  v.xPx = colred_sum(v.xPx, lds, bl, rg);
-  v.qx = colred_sum(v.qx, lds, bl, rg);
+#pragma unroll
+  for (int q = 0; q < NQ; q++) part[q][rg][bl] = v[q];
+  __syncthreads();
   if (rg != 0) return;  // wave 0 decides for its 64 columns
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    double r = part[q][0][bl];
+#pragma unroll
+    for (int w = 1; w < 4; w++) r = q < NQ_MAX ? fmax(r, part[q][w][bl]) : r + part[q][w][bl];
+    v[q] = r;
+  }
+  Norms nm{v[0], v[1], v[2], v[3], v[4], -v[5], v[6] * d.cinv, v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14],
+           v[15], v[16]};
   Ctrl *c = d.ctrl;
   bool newly = false;
   if (!d.c_done[b]) {
     double obj;
-    const int st = decide_status(d, v, obj);
-    d.c_pri[b] = v.pri;
-    d.c_dua[b] = v.dua;
+    const int st = decide_status(d, nm, obj);
+    d.c_pri[b] = nm.pri;
+    d.c_dua[b] = nm.dua;
     d.c_obj[b] = obj;
     if (st) {
       d.c_status[b] = st;
@@ -1658,7 +1817,7 @@ struct miosqp_qp_engine {
   hipGraphExec_t x_full = nullptr, x_tail = nullptr;
   int chunk = 25, tail_iters = 0;
   int tpr_pv = 64, tpr_pc = 64, tpr_tail = 64, tpr_pb = 64, tpr_pr = 64;
-  int bd_cfg = 44;  // batched dense kernels: 10*row_groups + k_slices
+  int bd_cfg = 0;  // batched dense kernels: 0 = fp64 matrix-core tiles, else 10*row_groups + k_slices (vector FMA)
   int tpr_ff = 256, tpr_fx = 64, tpr_fc = 64;  // product-form kernels: forward rows, x rows, constraint rows
   // pinned staging: [l | u | x0 | y0] in, [x | y] out, ctrl
   double *h_in = nullptr, *h_out = nullptr;
@@ -1856,6 +2015,12 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
 // which: 0 forward sweep, 1 backward sweep; workgroup shape from e->bd_cfg (row groups x k slices)
 void launch_bd(miosqp_qp_engine *e, int ntiles, int which) {
   const Dev &d = e->d;
+  if (e->bd_cfg == 0) {  // fp64 matrix-core tiles: 16 rows x 32 columns per workgroup
+    const int nbx = (d.n + 15) / 16, nbc = (d.M + 15) / 16, ncol = ntiles * (64 / BM_COLS);
+    if (which == 0) hipLaunchKernelGGL(kbm_fwd, dim3(nbx, ncol), dim3(BM_KS * 64), 0, e->stream, d);
+    else hipLaunchKernelGGL(kbm_bwd, dim3(nbx + nbc, ncol), dim3(BM_KS * 64), 0, e->stream, d);
+    return;
+  }
 #define BD(RG, KS)                                                                                         \
   do {                                                                                                     \
     constexpr int R = BdCfg<RG, KS>::ROWS, T = BdCfg<RG, KS>::THREADS;                                      \
@@ -1893,7 +2058,7 @@ int capture_chunk_b(miosqp_qp_engine *e, int iters, int ntiles, hipGraph_t *g, h
   for (int i = 0; i < iters; i++) launch_iteration_b(e, ntiles);
   hipLaunchKernelGGL(kb_check_con, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_check_var, dim3(2 * ((d.n + 3) / 4), ntiles), dim3(256), 0, e->stream, d);
-  hipLaunchKernelGGL(kb_check_decide, dim3(ntiles), dim3(1024), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_check_decide, dim3(ntiles), dim3(256), 0, e->stream, d);
   HIPCHK(hipStreamEndCapture(e->stream, g));
   HIPCHK(hipGraphInstantiate(x, *g, nullptr, nullptr, 0));
   return 0;
@@ -2214,6 +2379,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         }
       }
       if (const char *ev = getenv("MIOSQP_BD_CFG")) e->bd_cfg = atoi(ev);
+      if (const char *ev = getenv("MIOSQP_BM_ABLATE")) d.bm_ablate = atoi(ev);
       if (const char *ev = getenv("MIOSQP_FOLD_TPR")) {  // tuning hook: "fwd,x,c"
         int a = 0, b = 0, c = 0;
         if (sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3) {
