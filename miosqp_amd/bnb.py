@@ -277,6 +277,7 @@ class Workspace(object):
                 lower = None if np.isnan(r.lower[k]) else float(r.lower[k])
                 lf._absorb(int(r.status_val[k]), int(r.iter[k]), float(r.run_time[k]), r.x[k].copy(),
                            r.y[k].copy(), lower)
+                lf.digest = r.digest[k] if getattr(r, 'digest', None) is not None else None
         else:
             for lf in leaves:
                 lf.solve()

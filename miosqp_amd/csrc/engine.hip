@@ -104,6 +104,9 @@ struct Dev {
   double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_rx, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
   double *b_sm, *b_sn;      // 8 x M x Bs, 4 x n x Bs
   double *b_xfin, *b_yfin;  // unscaled answers, batch-fastest
+  double *b_xi, *b_xis;     // rounded candidates (node digest), unscaled / scaled
+  int *c_intinf, *c_nextvar;
+  double *c_hviol, *c_hobj;
   double *b_raw;            // node-major staging in:  l[B][M] | u[B][M] | x0[B][n] | y0[B][M]
   double *b_out;            // node-major staging out: x[B][n] | y[B][M]
   int *c_done, *c_status, *c_iter;
@@ -1731,30 +1734,85 @@ __global__ __launch_bounds__(1024) void kb_finish(Dev d, int B) {
       d.b_xfin[o] = fmin(fmax(d.b_xfin[o], lo), hi);
     }
   }
+  if (d.digest) {
+    // per column: is_int_feas + pick_nextvar + rounded candidate (workspace.py:245-272)
+    const bool okc = b < B && (st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED);
+    __syncthreads();
+    for (int i = rg; i < n; i += 16) d.b_xi[i * Bs + b] = d.b_xfin[i * Bs + b];
+    __syncthreads();
+    int cnt = 0, bestk = 0x7fffffff;
+    double best = -1.0;
+    for (int k = rg; k < d.n_int; k += 16) {
+      const size_t o = (size_t)d.i_idx[k] * Bs + b;
+      const double v = d.b_xfin[o], r = rint(v), f = fabs(v - r);
+      d.b_xi[o] = r;
+      cnt += f > d.eps_int;
+      if (f > best) { best = f; bestk = k; }
+    }
+    __syncthreads();
+    lds[rg * 64 + bl] = best;
+    __shared__ int lk[16 * 64], lc[16 * 64];
+    lk[rg * 64 + bl] = bestk;
+    lc[rg * 64 + bl] = cnt;
+    __syncthreads();
+    if (rg == 0) {
+      for (int w = 1; w < 16; w++) {
+        const double ob = lds[w * 64 + bl];
+        const int ok = lk[w * 64 + bl];
+        cnt += lc[w * 64 + bl];
+        if (ob > best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+      }
+      d.c_intinf[b] = okc ? cnt : -1;
+      d.c_nextvar[b] = okc && bestk != 0x7fffffff ? bestk : -1;
+    }
+    for (int i = rg; i < n; i += 16) d.b_xis[i * Bs + b] = d.Dinv[i] * d.b_xi[i * Bs + b];
+  }
   if (rg == 0 && d.c_status[b] == MIOSQP_QP_UNSOLVED) {
     d.c_status[b] = MIOSQP_QP_MAX_ITER_REACHED;
     d.c_iter[b] = d.ctrl->iter;
   }
 }
 
+// rounding heuristic per column: rows of A against the rounded candidates (workspace.py:232-243)
+__global__ __launch_bounds__(256) void kb_heur_rows(Dev d) {
+  BSETUP
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= d.M) return;
+  const double acc = brow_dot(d.pc_idx, d.pc_A, d.pc_ptr[row], d.pc_ptr[row + 1], d.b_xis + b, Bs);
+  const double z = d.Einv[row] * acc;
+  d.b_sm[row * Bs + b] = fmax(d.root_l[row] - d.eps_lin - z, z - d.root_u[row] - d.eps_lin);
+}
+
 __global__ __launch_bounds__(256) void kb_obj_rows(Dev d) {
   BSETUP
   const int row = blockIdx.x * 4 + wv;
   if (row >= d.n) return;
-  const double acc = brow_dot(d.pr_idx, d.pr_val, d.pr_ptr[row], d.pr_ptr[row + 1], d.b_xfin + b, Bs);
+  double acc, acc2;
+  brow_dot2(d.pr_idx, d.pr_val, d.pr_ptr[row], d.pr_ptr[row + 1], d.b_xfin + b, (d.digest ? d.b_xi : d.b_xfin) + b, Bs,
+            acc, acc2);
   d.b_sn[row * Bs + b] = d.b_xfin[row * Bs + b] * (0.5 * acc + d.qraw[row]);
+  if (d.digest) d.b_sn[(size_t)d.n * Bs + row * Bs + b] = d.b_xi[row * Bs + b] * (0.5 * acc2 + d.qraw[row]);
 }
 
 __global__ __launch_bounds__(1024) void kb_obj_sum(Dev d) {
   __shared__ double lds[16 * 64];
   const int tid = threadIdx.x, bl = tid & 63, rg = tid >> 6, b = blockIdx.x * 64 + bl;
   const size_t Bs = (size_t)d.Bs;
-  double s = 0;
+  double s = 0, s2 = 0, vmax = -1.7e308;
   for (int i = rg; i < d.n; i += 16) s += d.b_sn[i * Bs + b];
   s = colred_sum(s, lds, bl, rg);
+  if (d.digest) {
+    for (int i = rg; i < d.n; i += 16) s2 += d.b_sn[(size_t)d.n * Bs + i * Bs + b];
+    for (int j = rg; j < d.M; j += 16) vmax = fmax(vmax, d.b_sm[j * Bs + b]);
+    s2 = colred_sum(s2, lds, bl, rg);
+    vmax = colred_max(vmax, lds, bl, rg);
+  }
   if (rg == 0) {
     const int st = d.c_status[b];
-    d.c_lower[b] = (st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED) ? s : __builtin_nan("");
+    const bool ok = st == MIOSQP_QP_SOLVED || st == MIOSQP_QP_MAX_ITER_REACHED;
+    d.c_lower[b] = ok ? s : __builtin_nan("");
+    d.c_hobj[b] = ok && d.digest ? s2 : __builtin_nan("");
+    d.c_hviol[b] = ok && d.digest ? vmax : __builtin_nan("");
   }
 }
 
@@ -2076,7 +2134,8 @@ int alloc_batch(miosqp_qp_engine *e, int cap) {
   } while (0)
   ALB(b_l, M * Bs); ALB(b_u, M * Bs); ALB(b_x, n * Bs); ALB(b_z, M * Bs); ALB(b_y, M * Bs); ALB(b_wh, (M + n) * Bs);
   ALB(b_cv, n * Bs); ALB(b_ut, n * Bs); ALB(b_xt, n * Bs); ALB(b_dx, n * Bs); ALB(b_dy, M * Bs);
-  ALB(b_sm, 8 * M * Bs); ALB(b_sn, 4 * n * Bs); ALB(b_xfin, n * Bs); ALB(b_yfin, M * Bs);
+  ALB(b_sm, 8 * M * Bs); ALB(b_sn, 4 * n * Bs); ALB(b_xfin, n * Bs); ALB(b_yfin, M * Bs); ALB(b_xi, n * Bs); ALB(b_xis, n * Bs);
+  ALB(c_intinf, Bs); ALB(c_nextvar, Bs); ALB(c_hviol, Bs); ALB(c_hobj, Bs);
   ALB(b_raw, Bs * (3 * M + n)); ALB(b_out, Bs * (n + M));
   ALB(c_done, Bs); ALB(c_status, Bs); ALB(c_iter, Bs); ALB(c_pri, Bs); ALB(c_dua, Bs); ALB(c_obj, Bs);
   ALB(c_lower, Bs);
@@ -2084,8 +2143,8 @@ int alloc_batch(miosqp_qp_engine *e, int cap) {
   d.b_rx = d.b_wh + M * Bs;
   HIPCHK(hipHostMalloc((void **)&e->hb_in, sizeof(double) * Bs * (3 * M + n), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->hb_out, sizeof(double) * Bs * (n + M), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void **)&e->hb_int, sizeof(int) * 2 * Bs, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void **)&e->hb_dbl, sizeof(double) * 4 * Bs, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&e->hb_int, sizeof(int) * 4 * Bs, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&e->hb_dbl, sizeof(double) * 6 * Bs, hipHostMallocDefault));
   e->Bcap = (int)Bs;
   return 0;
 }
@@ -2134,6 +2193,7 @@ int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, co
   }
   if (!done && e->tail_iters > 0) HIPCHK(hipGraphLaunch(e->xb_tail[ntiles - 1], e->stream));
   hipLaunchKernelGGL(kb_finish, dim3(ntiles), dim3(1024), 0, e->stream, d, B);
+  if (d.digest) hipLaunchKernelGGL(kb_heur_rows, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_obj_rows, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_obj_sum, dim3(ntiles), dim3(1024), 0, e->stream, d);
   hipLaunchKernelGGL(kb_export, dim3((big + 3) / 4, ntiles), dim3(256), 0, e->stream, d, B);
@@ -2144,6 +2204,10 @@ int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, co
   HIPCHK(hipMemcpyAsync(e->hb_dbl + B, d.c_dua, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->hb_dbl + 2 * B, d.c_obj, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->hb_dbl + 3 * B, d.c_lower, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_dbl + 4 * B, d.c_hviol, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_dbl + 5 * B, d.c_hobj, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_int + 2 * B, d.c_intinf, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_int + 3 * B, d.c_nextvar, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   memcpy(x_out, e->hb_out, sizeof(double) * B * n);
@@ -2158,8 +2222,10 @@ int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, co
     info[b].dua_res = e->hb_dbl[B + b];
     info[b].obj_val = e->hb_dbl[2 * B + b];
     info[b].lower = e->hb_dbl[3 * B + b];
-    info[b].int_inf = info[b].nextvar = -1;
-    info[b].heur_viol = info[b].heur_obj = __builtin_nan("");
+    info[b].int_inf = d.digest ? e->hb_int[2 * B + b] : -1;
+    info[b].nextvar = d.digest ? e->hb_int[3 * B + b] : -1;
+    info[b].heur_viol = e->hb_dbl[4 * B + b];
+    info[b].heur_obj = e->hb_dbl[5 * B + b];
     info[b].run_time = wall_s / B;  // the wave's wall time, shared equally
     info[b].device_time = 1e-3 * ms / B;
   }

@@ -177,7 +177,13 @@ class OSQP(object):
                                                     _lib.as_d(y), infos), "solve_batch")
         if rc == 1:
             raise ValueError("Lower bound must be lower than or equal to upper bound")
+        digests = [None] * B
+        for k, i in enumerate(infos):
+            if i.int_inf >= 0:
+                digests[k] = types.SimpleNamespace(int_inf=i.int_inf, nextvar=i.nextvar,
+                                                   heur_feasible=i.heur_viol <= 0.0, heur_obj=i.heur_obj)
         return types.SimpleNamespace(
+            digest=digests,
             x=x, y=y, status_val=np.array([i.status_val for i in infos]),
             iter=np.array([i.iter for i in infos]), lower=np.array([i.lower for i in infos]),
             run_time=np.array([i.run_time for i in infos]), infos=infos)

@@ -277,6 +277,7 @@ def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold):
     g.setup(pr["P"], pr["q"], A, l, u, max_batch=64, fold=fold, **problems.QP_SETTINGS)  # 64 < count: slices
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
     g.set_integer_rows(pr["i_idx"], m)
+    g.set_root(l, u, 1e-3, 1e-3)  # node digest on: integrality, branching variable, rounding heuristic
     L = np.stack([lf.l for lf in leaves]); U = np.stack([lf.u for lf in leaves])
     X = np.stack([lf.x for lf in leaves]); Y = np.stack([lf.y for lf in leaves])
     rb = g.solve_batch(L, U, X, Y)
@@ -297,8 +298,23 @@ def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold):
             lo = 0.5 * xo.dot(pr["P"].dot(xo)) + pr["q"].dot(xo)
             assert abs(rb.lower[k] - lo) <= 1e-9 * max(1.0, abs(lo))
             assert abs(rb.lower[k] - r1.lower) <= 1e-9 * max(1.0, abs(lo))
+            # digest: batched == single node == numpy restatement of workspace.py:245-272, 232-243
+            db, d1 = rb.digest[k], r1.digest
+            xi_all = xo[ii]
+            frac = np.abs(xi_all - np.round(xi_all))
+            assert db.int_inf == d1.int_inf == int(np.sum(frac > 1e-3))
+            if frac.max() > 1e-6:
+                assert db.nextvar == d1.nextvar == int(np.argmax(frac))
+            xr = xo.copy()
+            xr[ii] = np.round(xo[ii])
+            zz = A.dot(xr)
+            margin = np.max(np.maximum(l - 1e-3 - zz, zz - u - 1e-3))
+            if abs(margin) > 1e-7:
+                assert db.heur_feasible == d1.heur_feasible == bool(margin <= 0)
+            ho = 0.5 * xr.dot(pr["P"].dot(xr)) + pr["q"].dot(xr)
+            assert abs(db.heur_obj - ho) <= 1e-8 * max(1.0, abs(ho)) and abs(d1.heur_obj - ho) <= 1e-8 * max(1.0, abs(ho))
         else:
-            assert np.isnan(rb.lower[k])
+            assert np.isnan(rb.lower[k]) and rb.digest[k] is None
     # a second identical call is bit-identical
     rb2 = g.solve_batch(L, U, X, Y)
     np.testing.assert_array_equal(rb.x, rb2.x)
