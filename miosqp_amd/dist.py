@@ -24,8 +24,17 @@ class LocalComm(object):
     def incumbent(self, value, x):
         return value, 0, x
 
-    def exchange(self, value, x, nleaves):
-        return value, 0, x, nleaves
+    def exchange(self, value, x, nleaves, have=None):
+        return value, 0, None, nleaves
+
+    def leaf_counts(self):
+        return None
+
+    def send(self, arr, dst):
+        raise RuntimeError("single rank")
+
+    def recv(self, size, src):
+        raise RuntimeError("single rank")
 
     def sum(self, arr):
         return np.asarray(arr, dtype=np.float64)
@@ -53,6 +62,7 @@ class TorchComm(object):
         allv = t.empty(2 * self.world, dtype=t.float64, device=self.device)
         self.dist.all_gather_into_tensor(allv, mine)
         tab = allv.cpu().numpy().reshape(self.world, 2)
+        self._counts = [int(round(c)) for c in tab[:, 1]]
         owner = int(np.argmin(tab[:, 0]))
         best = float(tab[owner, 0])
         total = int(round(tab[:, 1].sum()))
@@ -68,6 +78,18 @@ class TorchComm(object):
     def incumbent(self, value, x):
         best, owner, xb, _ = self.exchange(value, x, 0)
         return best, owner, (x if xb is None else xb)
+
+    def leaf_counts(self):
+        """Open leaves per rank as of the last exchange()."""
+        return list(self._counts)
+
+    def send(self, arr, dst):
+        self.dist.send(self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device), dst=dst)
+
+    def recv(self, size, src):
+        buf = self.torch.empty(size, dtype=self.torch.float64, device=self.device)
+        self.dist.recv(buf, src=src)
+        return buf.cpu().numpy()
 
     def sum(self, arr):
         t = self.torch
@@ -95,6 +117,8 @@ class ShardedSearch(object):
         self.iters = 0
         self.replicated = True
         self.global_upper = np.inf
+        self.rebalance = True
+        self.moved = 0
 
     def begin_instance(self):
         """Call after MIOSQP.update_vectors (new root on every rank)."""
@@ -184,7 +208,44 @@ class ShardedSearch(object):
                 w.upper_glob = best
                 w.x = x
                 w.prune()
+        self._rebalance()
         return total
+
+    def _rebalance(self):
+        """A rank that ran dry receives one leaf from the rank holding most (point to point, 2M+n+M+2
+        doubles).  Every rank derives the same transfer plan from the gathered leaf counts (taken
+        before this wave's pruning, which is why a donor re-checks that it still has two leaves)."""
+        counts = self.comm.leaf_counts()
+        if not counts or not self.rebalance:
+            return
+        w, me = self.work, self.comm.rank
+        plan = []
+        for r in range(len(counts)):
+            if counts[r] == 0:
+                donor = int(np.argmax(counts))
+                if counts[donor] >= 2:
+                    plan.append((donor, r))
+                    counts[donor] -= 1
+                    counts[r] += 1
+        n, M = w.data.n, w.data.m + w.data.n_int
+        size = 3 * M + n + 3
+        for donor, recv in plan:
+            if me == donor:
+                if len(w.leaves) >= 2:
+                    lf = w.leaves.pop()
+                    msg = np.concatenate([lf.l, lf.u, lf.x, lf.y, [float(lf.depth), float(lf.lower), 1.0]])
+                else:  # pruned in the meantime: send an empty token so the receiver does not hang
+                    msg = np.zeros(size)
+                self.comm.send(msg, recv)
+                self.moved += 1
+            elif me == recv:
+                msg = self.comm.recv(size, donor)
+                if msg[-1] == 1.0:
+                    from miosqp_amd.bnb import Node
+                    w.leaves.append(Node(w.data, msg[:M].copy(), msg[M:2 * M].copy(), w.solver,
+                                         depth=int(msg[-3]), lower=float(msg[-2]),
+                                         x0=msg[2 * M:2 * M + n].copy(), y0=msg[2 * M + n:3 * M + n].copy(),
+                                         constant=w.constant))
 
     def open_leaves(self):
         return int(self.comm.sum([len(self.work.leaves)])[0])

@@ -31,10 +31,10 @@ def main():
     s.deal()
     mine = len(model.work.leaves)
     waves = s.run(nodes_per_rank=per_rank)
-    tot = comm.sum([s.nodes, s.iters, mine])
+    tot = comm.sum([s.nodes, s.iters, mine, s.moved])
     w = model.work
     rec = dict(rank=comm.rank, upper=w.upper_glob, x=list(map(float, w.x)), status=w.status, waves=waves,
-               nodes_total=float(tot[0]), iters_total=float(tot[1]), dealt_total=float(tot[2]),
+               nodes_total=float(tot[0]), iters_total=float(tot[1]), dealt_total=float(tot[2]), moved_total=float(tot[3]),
                leaves_before_deal=before)
     with open("%s.%d" % (out_path, comm.rank), "w") as f:
         json.dump(rec, f)
