@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""The reference's random-MIQP benchmark grid on the MI355X engine.
+
+Same problem grid, generator recipe, settings and CSV columns as
+/root/reference/examples/random_miqp/run_example.py:155-216 (problem set 1: n in {10..150},
+10 repeats, density 0.7, seed 0), minus the GUROBI columns (GUROBI / mathprogbasepy are not part
+of this build).  Times are milliseconds like the reference's (`1e3 * run_time`);
+`t_miosqp_osqp_avg` is the relaxation solver's share of the run time in percent
+(run_example.py:142-143).
+
+    python examples/random_miqp.py [--repeat 10] [--out results/random_miqp.csv] [--backend hip|oracle]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from miosqp_amd import bnb, problems  # noqa: E402
+
+N_ARR = [10, 10, 50, 50, 100, 100, 150, 150]
+M_ARR = [5, 100, 25, 200, 50, 200, 100, 300]
+P_ARR = [2, 2, 5, 10, 2, 15, 5, 20]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--repeat", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "results", "random_miqp.csv"))
+    ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
+    args = ap.parse_args()
+    backend = None
+    if args.backend == "oracle":  # CPU restatement, for side-by-side numbers only
+        from oracle import oracle as backend
+    np.random.seed(args.seed)
+    rows = []
+    for n, m, p in zip(N_ARR, M_ARR, P_ARR):
+        t, share, iters = [], [], []
+        for _ in range(args.repeat):
+            pr = problems.random_miqp(n, m, p, density=0.7, reseed=False)
+            model = bnb.MIOSQP(backend=backend)
+            model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                        dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+            res = model.solve()
+            if res.status != bnb.MI_SOLVED:
+                print("warning: n=%d m=%d p=%d ended with status %r" % (n, m, p, res.status))
+            t.append(1e3 * res.run_time)
+            share.append(100 * res.osqp_solve_time / res.run_time)
+            iters.append(res.osqp_iter_avg)
+        rows.append((n, m, p, np.mean(t), np.std(t), np.max(t), np.mean(share), np.mean(iters)))
+        print("n=%4d m=%4d p=%3d  t_avg %9.2f ms  t_std %8.2f  t_max %9.2f  osqp share %5.1f %%  iters/node %6.1f" % rows[-1])
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        f.write("n,m,p,t_miosqp_avg,t_miosqp_std,t_miosqp_max,t_miosqp_osqp_avg,osqp_iter_avg\n")
+        for r in rows:
+            f.write("%d,%d,%d,%.4f,%.4f,%.4f,%.2f,%.1f\n" % r)
+    print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()
