@@ -1866,7 +1866,9 @@ struct miosqp_qp_engine {
   miosqp::Scaled sc;
   miosqp::Factor fa;
   Dev d{};
-  std::vector<void *> allocs;
+  std::vector<void *> allocs;  // pool chunks
+  char *pool_base = nullptr;
+  size_t pool_cap = 0, pool_used = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
   double loop_ms = 0.0;
@@ -1904,19 +1906,39 @@ struct miosqp_qp_engine {
 
 namespace {
 
+// Device memory comes from a few large zero-filled chunks (one hipMalloc per chunk instead of one
+// per array: setup of a small problem is dominated by allocation calls otherwise).
+int pool_reserve(miosqp_qp_engine *e, size_t bytes) {
+  void *p = nullptr;
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  HIPCHK(hipMalloc(&p, bytes));
+  HIPCHK(hipMemset(p, 0, bytes));
+  e->allocs.push_back(p);
+  e->pool_base = (char *)p;
+  e->pool_cap = bytes;
+  e->pool_used = 0;
+  return 0;
+}
+int pool_alloc(miosqp_qp_engine *e, void **out, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (e->pool_used + bytes > e->pool_cap) {
+    int rc = pool_reserve(e, bytes > ((size_t)8 << 20) ? bytes : ((size_t)8 << 20));
+    if (rc) return rc;
+  }
+  *out = e->pool_base + e->pool_used;
+  e->pool_used += bytes;
+  return 0;
+}
 template <typename T>
 int dalloc(miosqp_qp_engine *e, T **p, size_t count) {
-  HIPCHK(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
-  HIPCHK(hipMemset(*p, 0, (count ? count : 1) * sizeof(T)));
-  e->allocs.push_back(*p);
-  return 0;
+  return pool_alloc(e, (void **)p, (count ? count : 1) * sizeof(T));
 }
 template <typename T>
 int dupload(miosqp_qp_engine *e, const std::vector<T> &h, const T **p) {
   T *q = nullptr;
-  int rc = upload(h, &q);
+  int rc = pool_alloc(e, (void **)&q, (h.size() + 64) * sizeof(T));  // slack: tile loads may overshoot a row
   if (rc) return rc;
-  e->allocs.push_back(q);
+  if (h.size()) HIPCHK(hipMemcpy(q, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   *p = q;
   return 0;
 }
@@ -2127,6 +2149,10 @@ int alloc_batch(miosqp_qp_engine *e, int cap) {
   const size_t n = e->n, M = e->M;
   const size_t Bs = ((size_t)cap + 63) & ~(size_t)63;
   d.Bs = (int)Bs;
+  {
+    int rc0 = pool_reserve(e, Bs * ((size_t)24 * M + (size_t)16 * n + 64) * 8 + ((size_t)1 << 16));
+    if (rc0) return rc0;
+  }
 #define ALB(field, count)                            \
   do {                                               \
     int rc__ = dalloc(e, &d.field, (size_t)(count)); \
@@ -2347,6 +2373,15 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   d.n = n; d.M = M; d.ld = f.ld; d.n_int = 0; d.m_orig = M;
   d.rho = s->rho; d.rho_inv = 1.0 / s->rho; d.sigma = s->sigma; d.alpha = s->alpha; d.eps_abs = s->eps_abs; d.eps_rel = s->eps_rel;
   d.eps_pinf = s->eps_prim_inf; d.eps_dinf = s->eps_dual_inf; d.c = e->sc.c; d.cinv = e->sc.cinv;
+  {
+    // one chunk for everything this setup will place on the device
+    const size_t np2 = f.panel_by_var.idx.size() + f.panel_by_con.idx.size();
+    size_t est = np2 * (4 + 16) + 2 * f.Linv.size() * 8 + (f.Pbar.idx.size() + f.Praw.idx.size()) * 12 +
+                 ((size_t)60 * n + (size_t)60 * M) * 8 + ((size_t)n * ((M + n + 8)) + (size_t)M * (n + 8)) * 8 +
+                 200 * 512 + ((size_t)1 << 16);
+    int rc0 = pool_reserve(e, est);
+    if (rc0) { miosqp_qp_cleanup(e); return rc0; }
+  }
 #define UP(vec, field)                                   \
   do {                                                   \
     int rc__ = dupload(e, vec, &d.field);                \
@@ -2461,9 +2496,11 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->chunk = e->st.check_termination;
   e->tail_iters = e->st.max_iter % e->chunk;
   HIPCHK(hipStreamSynchronize(e->stream));
-  int rc = capture_chunk(e, e->chunk, &e->g_full, &e->x_full);
-  if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
-  if (rc) { miosqp_qp_cleanup(e); return rc; }
+  if (!e->resident) {  // the LDS-resident solver needs no captured chunk
+    int rc = capture_chunk(e, e->chunk, &e->g_full, &e->x_full);
+    if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
+    if (rc) { miosqp_qp_cleanup(e); return rc; }
+  }
   *out = e;
   return 0;
 }
