@@ -30,10 +30,7 @@ class LocalComm(object):
     def leaf_counts(self):
         return None
 
-    def send(self, arr, dst):
-        raise RuntimeError("single rank")
-
-    def recv(self, size, src):
+    def move(self, arr, size, src):
         raise RuntimeError("single rank")
 
     def sum(self, arr):
@@ -83,12 +80,15 @@ class TorchComm(object):
         """Open leaves per rank as of the last exchange()."""
         return list(self._counts)
 
-    def send(self, arr, dst):
-        self.dist.send(self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device), dst=dst)
-
-    def recv(self, size, src):
-        buf = self.torch.empty(size, dtype=self.torch.float64, device=self.device)
-        self.dist.recv(buf, src=src)
+    def move(self, arr, size, src):
+        """One leaf record from rank `src` to everybody (a broadcast on the world communicator: every
+        rank takes part, so no extra point-to-point communicator is ever created); `arr` is only
+        read on `src`."""
+        if self.rank == src:
+            buf = self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
+        else:
+            buf = self.torch.empty(size, dtype=self.torch.float64, device=self.device)
+        self.dist.broadcast(buf, src=src)
         return buf.cpu().numpy()
 
     def sum(self, arr):
@@ -117,7 +117,8 @@ class ShardedSearch(object):
         self.iters = 0
         self.replicated = True
         self.global_upper = np.inf
-        self.rebalance = True
+        import os
+        self.rebalance = os.environ.get("MIOSQP_REBALANCE", "1") != "0"
         self.moved = 0
 
     def begin_instance(self):
@@ -212,9 +213,10 @@ class ShardedSearch(object):
         return total
 
     def _rebalance(self):
-        """A rank that ran dry receives one leaf from the rank holding most (point to point, 2M+n+M+2
-        doubles).  Every rank derives the same transfer plan from the gathered leaf counts (taken
-        before this wave's pruning, which is why a donor re-checks that it still has two leaves)."""
+        """A rank that ran dry receives one leaf (3M+n+3 doubles) from the rank holding most.  Every
+        rank derives the same transfer plan from the gathered leaf counts (taken before this wave's
+        pruning, which is why a donor re-checks that it still has two leaves) and takes part in the
+        broadcast that carries the record; only the receiver keeps it."""
         counts = self.comm.leaf_counts()
         if not counts or not self.rebalance:
             return
@@ -230,16 +232,16 @@ class ShardedSearch(object):
         n, M = w.data.n, w.data.m + w.data.n_int
         size = 3 * M + n + 3
         for donor, recv in plan:
+            msg = None
             if me == donor:
                 if len(w.leaves) >= 2:
                     lf = w.leaves.pop()
                     msg = np.concatenate([lf.l, lf.u, lf.x, lf.y, [float(lf.depth), float(lf.lower), 1.0]])
-                else:  # pruned in the meantime: send an empty token so the receiver does not hang
+                    self.moved += 1
+                else:  # pruned in the meantime: an empty token keeps the collective matched
                     msg = np.zeros(size)
-                self.comm.send(msg, recv)
-                self.moved += 1
-            elif me == recv:
-                msg = self.comm.recv(size, donor)
+            msg = self.comm.move(msg, size, donor)
+            if me == recv:
                 if msg[-1] == 1.0:
                     from miosqp_amd.bnb import Node
                     w.leaves.append(Node(w.data, msg[:M].copy(), msg[M:2 * M].copy(), w.solver,
