@@ -2338,6 +2338,11 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     g_err = "setup: bad argument";
     return MIOSQP_EARG;
   }
+  if (M == 0) {
+    // miOSQP always has rows: data.py:5-33 appends one identity row per integer variable
+    g_err = "setup: the engine needs at least one constraint row (M >= 1)";
+    return MIOSQP_EARG;
+  }
   for (int i = 0; i < M; i++)
     if (l[i] > u[i]) {
       g_err = "setup: lower bound above upper bound";

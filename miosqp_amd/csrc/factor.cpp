@@ -6,10 +6,24 @@
 #include <cmath>
 #include <functional>
 #include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace miosqp {
 
 namespace {
+
+struct StageTimer {  // MIOSQP_SETUP_TIMING=1 prints the host setup stages
+  bool on = getenv("MIOSQP_SETUP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[miosqp setup] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 
 constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;
 
@@ -159,6 +173,7 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
 bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
                   const double *Px_raw, double rho, double sigma, Factor &f, std::string &err) {
   const int n = s.n, M = s.M;
+  StageTimer tm;
   f.n = n;
   f.M = M;
   f.rho = rho;
@@ -181,6 +196,7 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
     pack_rows(M, n, bycon, f.panel_by_con, &f.A_val);
     f.nnz_panel = f.panel_by_var.nnz;
   }
+  tm.lap("panel rows");
   // ---- symmetric matrices by row ----------------------------------------------------------
   {
     std::vector<std::vector<Triplet>> rows(n);
@@ -201,6 +217,7 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
       }
     pack_rows(n, n, rows, f.Praw, nullptr);
   }
+  tm.lap("P rows");
   // ---- Schur complement S = Pbar + sigma I + rho Abar^T Abar (dense, lower, row-major) -----
   std::vector<double> S((size_t)n * ld, 0.0);
   for (int j = 0; j < n; j++)
@@ -225,6 +242,7 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
     });
     // padding entries carry value 0, so a repeated last column adds nothing
   }
+  tm.lap("Schur complement");
   // ---- blocked right-looking LDL^T of S (in place: strict lower = L22, diag = D22) ------
   std::vector<double> d(n);
   const int nb = 64;
@@ -279,6 +297,7 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
     });
   }
   if (!ok) return false;
+  tm.lap("dense LDL^T");
   f.d2inv.resize(n);
   for (int j = 0; j < n; j++) f.d2inv[j] = 1.0 / d[j];
   f.nnz_tail = (int64_t)n * (n - 1) / 2;
@@ -308,9 +327,11 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
       }
     });
   }
+  tm.lap("triangular inverse");
   f.LinvT.assign((size_t)n * ld, 0.0);
   for (int i = 0; i < n; i++)
     for (int j = 0; j < i; j++) f.LinvT[(size_t)j * ld + i] = f.Linv[(size_t)i * ld + j];
+  tm.lap("transpose");
   return true;
 }
 

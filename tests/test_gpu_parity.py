@@ -403,3 +403,59 @@ def test_device_digest_equals_host_logic(n, m, p, seed):
         assert abs(a[6] - b[6]) <= 1e-9 * max(1.0, abs(a[6])) or (np.isinf(a[6]) and np.isinf(b[6]))
     assert abs(out[0][1] - out[1][1]) <= 1e-9 * max(1.0, abs(out[0][1]))
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=0, atol=1e-9)
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 (n=5000, m=10000, p=2500, 1 % dense A; factor form, 13 M factor entries): the
+    oracle would take minutes here, so the full size is checked through size-independent properties:
+    the KKT certificate at the solver's own tolerances, bit-identical reruns, batch == node by node."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(**problems.CONFIGS["cfg5"], seed=0)
+    A, l, u = problems.extended(pr)
+    n, M, m = 5000, A.shape[0], 10000
+    g = qp.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, max_batch=64, **problems.QP_SETTINGS)
+    g.set_integer_rows(pr["i_idx"], m)
+    fs = g.factor_stats()
+    assert fs["nnz_L"] == A.nnz + n * (n - 1) // 2 and not fs["fold"]
+    g.warm_start(x=np.zeros(n), y=np.zeros(M))
+    r = g.solve()
+    assert r.info.status_val == 1 and r.info.iter % 25 == 0
+    c = kkt_certificate(pr["P"], pr["q"], A, l, u, r.x, r.y)
+    zc = np.clip(A.dot(r.x), l, u)
+    ep, ed = osqp_tolerances(pr["P"], pr["q"], A, r.x, r.y, zc, 1e-3, 1e-3)
+    assert c["pri"] <= ep and c["dua"] <= ed and c["stray"] == 0.0
+    assert abs(c["dua"] - r.info.dua_res) <= 1e-9 + 1e-6 * c["dua"]
+    assert abs(c["obj"] - r.info.obj_val) <= 1e-9 * max(1.0, abs(c["obj"]))
+    ii = pr["i_idx"]
+    xi = r.x[ii]
+    k = int(np.argmax(np.abs(xi - np.round(xi))))
+    L2, U2 = np.stack([l, l]), np.stack([u, u])
+    U2[0, m + k] = np.floor(xi[k])
+    L2[1, m + k] = np.ceil(xi[k])
+    X0, Y0 = np.stack([r.x, r.x]), np.stack([r.y, r.y])
+    a = [g.solve_node(L2[i], U2[i], X0[i], Y0[i]) for i in (0, 1)]
+    b = [g.solve_node(L2[i], U2[i], X0[i], Y0[i]) for i in (0, 1)]
+    rb = g.solve_batch(L2, U2, X0, Y0)
+    for i in (0, 1):
+        assert a[i].iter == b[i].iter and a[i].lower == b[i].lower
+        np.testing.assert_array_equal(a[i].x, b[i].x)
+        assert (rb.status_val[i], rb.iter[i]) == (a[i].status_val, a[i].iter)
+        assert rel(rb.x[i], a[i].x) <= SOL_TOL and rel(rb.y[i], a[i].y) <= SOL_TOL
+        lo = 0.5 * a[i].x.dot(pr["P"].dot(a[i].x)) + pr["q"].dot(a[i].x)
+        assert abs(a[i].lower - lo) <= 1e-9 * max(1.0, abs(lo))
+        xi2 = a[i].x[ii]
+        assert np.all(xi2 >= L2[i][m:] - 0) and np.all(xi2 <= U2[i][m:] + 0)
+
+
+def test_setup_rejects_bad_input():
+    import scipy.sparse as spa
+    from miosqp_amd import qp
+    P = spa.csc_matrix(np.eye(3))
+    with pytest.raises(RuntimeError, match="at least one constraint"):
+        qp.OSQP().setup(P, np.zeros(3), spa.csc_matrix((0, 3)), np.zeros(0), np.zeros(0))
+    with pytest.raises(RuntimeError, match="non-positive pivot|KKT"):
+        qp.OSQP().setup(spa.csc_matrix(-50.0 * np.eye(3)), np.zeros(3), spa.csc_matrix(np.eye(3)), -np.ones(3),
+                        np.ones(3), scaling=0)
+    with pytest.raises(ValueError):
+        qp.OSQP().setup(P, np.zeros(3), spa.csc_matrix(np.eye(3)), -np.ones(3), np.ones(3), adaptive_rho=True)
