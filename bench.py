@@ -220,7 +220,7 @@ def main():
         out["config"]["instances_in_timed_region"] = instances
         if batched is not None and batched["lockstep_iters"] > 0:
             bk = []
-            bnames = ["kbd_fwd", "kbd_bwd"] if fs["fold"] else ["kb_" + k[2:] for k in KERNELS]
+            bnames = ["kbm_fwd", "kbm_bwd"] if fs["fold"] else ["kb_" + k[2:] for k in KERNELS]
             for k, nm in enumerate(bnames):
                 us, by = eng.time_kernel(10 + k, 30)
                 bk.append(dict(kernel=nm, usec=round(us, 2), bytes=by, gbs=round(by / us * 1e-3, 1)))

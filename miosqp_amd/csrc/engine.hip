@@ -105,6 +105,7 @@ struct Dev {
   double *b_sm, *b_sn;      // 8 x M x Bs, 4 x n x Bs
   double *b_xfin, *b_yfin;  // unscaled answers, batch-fastest
   double *b_xi, *b_xis;     // rounded candidates (node digest), unscaled / scaled
+  double *b_part;           // partial reductions of the batched termination test
   int *c_intinf, *c_nextvar;
   double *c_hviol, *c_hobj;
   double *b_raw;            // node-major staging in:  l[B][M] | u[B][M] | x0[B][n] | y0[B][M]
@@ -1565,19 +1566,21 @@ __device__ __forceinline__ double op_add(double a, double b) { return a + b; }
 COLRED(colred_max, fmax, 0)
 COLRED(colred_sum, op_add, 0)
 
-// 256 threads = 64 columns x 4 row groups; all 17 quantities meet in LDS in ONE pass
-__global__ __launch_bounds__(256) void kb_check_decide(Dev d) {
+// Stage 1 of the batched decision: grid (column tiles, KR row slices); every workgroup folds its
+// slice of rows for 64 columns and 17 quantities into b_part[tile][slice][q][64].
+constexpr int KR = 32;
+__global__ __launch_bounds__(256) void kb_check_reduce(Dev d) {
   if (d.ctrl->done) return;
   __shared__ double part[NQ][4][64];
   const int n = d.n, M = d.M, tid = threadIdx.x, bl = tid & 63, rg = tid >> 6;
-  const int b = blockIdx.x * 64 + bl;
+  const int b = blockIdx.x * 64 + bl, sl = blockIdx.y;
   const size_t Bs = (size_t)d.Bs, MB = (size_t)M * Bs, NB = (size_t)n * Bs;
   double v[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) v[q] = 0.0;
   v[4] = -1.7e308;
   v[5] = -1.7e308;
-  for (int j = rg; j < M; j += 4) {
+  for (int j = sl * 4 + rg; j < M; j += 4 * KR) {
     const size_t o = j * Bs + b;
     v[0] = fmax(v[0], fabs(d.b_sm[0 * MB + o]));
     v[1] = fmax(v[1], fabs(d.b_sm[1 * MB + o]));
@@ -1587,7 +1590,7 @@ __global__ __launch_bounds__(256) void kb_check_decide(Dev d) {
     v[5] = fmax(v[5], -d.b_sm[7 * MB + o]);
     v[13] += d.b_sm[5 * MB + o];
   }
-  for (int i = rg; i < n; i += 4) {
+  for (int i = sl * 4 + rg; i < n; i += 4 * KR) {
     const size_t o = i * Bs + b;
     const double di = d.Dinv[i], px = d.b_sn[0 * NB + o], aty = d.b_sn[2 * NB + o], q = d.q[i], x = d.b_x[o],
                  dx = d.b_dx[o];
@@ -1605,13 +1608,29 @@ __global__ __launch_bounds__(256) void kb_check_decide(Dev d) {
 #pragma unroll
   for (int q = 0; q < NQ; q++) part[q][rg][bl] = v[q];
   __syncthreads();
-  if (rg != 0) return;  // wave 0 decides for its 64 columns
+  if (rg != 0) return;
+  double *out = d.b_part + ((size_t)(blockIdx.x * KR + sl) * NQ) * 64;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
     double r = part[q][0][bl];
 #pragma unroll
     for (int w = 1; w < 4; w++) r = q < NQ_MAX ? fmax(r, part[q][w][bl]) : r + part[q][w][bl];
-    v[q] = r;
+    out[q * 64 + bl] = r;
+  }
+}
+
+// Stage 2: one wave per column tile combines the KR slices in slice order and decides
+__global__ __launch_bounds__(64) void kb_check_decide(Dev d) {
+  if (d.ctrl->done) return;
+  const int bl = threadIdx.x, b = blockIdx.x * 64 + bl;
+  double v[NQ];
+  const double *in = d.b_part + ((size_t)blockIdx.x * KR * NQ) * 64;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) v[q] = in[q * 64 + bl];
+  for (int sl = 1; sl < KR; sl++) {
+    const double *p = in + (size_t)sl * NQ * 64;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) v[q] = q < NQ_MAX ? fmax(v[q], p[q * 64 + bl]) : v[q] + p[q * 64 + bl];
   }
   Norms nm{v[0], v[1], v[2], v[3], v[4], -v[5], v[6] * d.cinv, v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14],
            v[15], v[16]};
@@ -2138,7 +2157,8 @@ int capture_chunk_b(miosqp_qp_engine *e, int iters, int ntiles, hipGraph_t *g, h
   for (int i = 0; i < iters; i++) launch_iteration_b(e, ntiles);
   hipLaunchKernelGGL(kb_check_con, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_check_var, dim3(2 * ((d.n + 3) / 4), ntiles), dim3(256), 0, e->stream, d);
-  hipLaunchKernelGGL(kb_check_decide, dim3(ntiles), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_check_reduce, dim3(ntiles, KR), dim3(256), 0, e->stream, d);
+  hipLaunchKernelGGL(kb_check_decide, dim3(ntiles), dim3(64), 0, e->stream, d);
   HIPCHK(hipStreamEndCapture(e->stream, g));
   HIPCHK(hipGraphInstantiate(x, *g, nullptr, nullptr, 0));
   return 0;
@@ -2162,6 +2182,7 @@ int alloc_batch(miosqp_qp_engine *e, int cap) {
   ALB(b_cv, n * Bs); ALB(b_ut, n * Bs); ALB(b_xt, n * Bs); ALB(b_dx, n * Bs); ALB(b_dy, M * Bs);
   ALB(b_sm, 8 * M * Bs); ALB(b_sn, 4 * n * Bs); ALB(b_xfin, n * Bs); ALB(b_yfin, M * Bs); ALB(b_xi, n * Bs); ALB(b_xis, n * Bs);
   ALB(c_intinf, Bs); ALB(c_nextvar, Bs); ALB(c_hviol, Bs); ALB(c_hobj, Bs);
+  ALB(b_part, (Bs / 64) * 32 * 17 * 64);
   ALB(b_raw, Bs * (3 * M + n)); ALB(b_out, Bs * (n + M));
   ALB(c_done, Bs); ALB(c_status, Bs); ALB(c_iter, Bs); ALB(c_pri, Bs); ALB(c_dua, Bs); ALB(c_obj, Bs);
   ALB(c_lower, Bs);
