@@ -1419,6 +1419,9 @@ __device__ __forceinline__ void bm_tile(const double *__restrict__ A, int ld, in
   const double *__restrict__ vr = V + r;
 #pragma unroll
   for (int t = 0; t < BM_NT; t++) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double4_t acc2[BM_NT];
+#pragma unroll
+  for (int t = 0; t < BM_NT; t++) acc2[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int k0 = kbeg & ~15;
   // software pipeline: operands of chunk c+1 are in flight while chunk c feeds the matrix core
   double a[4], b[BM_NT][4], an[4], bn[BM_NT][4];
@@ -1456,9 +1459,12 @@ __device__ __forceinline__ void bm_tile(const double *__restrict__ A, int ld, in
       }
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < 4; s += 2) {  // two accumulator sets: four independent matrix-core chains
 #pragma unroll
         for (int t = 0; t < BM_NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[t][s], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < BM_NT; t++)
+          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b[t][s + 1], acc2[t], 0, 0, 0);
       }
     }
     if (kn < kend) {
@@ -1470,6 +1476,8 @@ __device__ __forceinline__ void bm_tile(const double *__restrict__ A, int ld, in
       }
     }
   }
+#pragma unroll
+  for (int t = 0; t < BM_NT; t++) acc[t] += acc2[t];
 }
 
 // adds the KS partial tiles in wave order; thread e < 512 ends up with output element e:
