@@ -90,8 +90,8 @@ struct Dev {
   double *raw_l, *raw_u, *raw_x, *raw_y, *out_x, *out_y;
   Ctrl *ctrl;
   // ---- folded (product-form) factor: rows of L^-1, see factor.hpp ----
-  const double *f_rows, *f_GmT;
-  int ldf, ldn;
+  const double *f_rows, *f_GmT, *f_Ad, *f_Atd, *f_Pd;
+  int ldf, ldn, ldm;
   double *rx;  // sigma x - q, kept right behind wh so that [wh | rx] is one contiguous vector
   // node digest: rounded candidate (unscaled / scaled), root bounds, tolerances
   double *xi, *xis, *root_l, *root_u;
@@ -1574,6 +1574,65 @@ __device__ __forceinline__ double op_add(double a, double b) { return a + b; }
 COLRED(colred_max, fmax, 0)
 COLRED(colred_sum, op_add, 0)
 
+// batched termination test on the dense copies, same matrix-core tiles as the sweeps
+__global__ __launch_bounds__(BM_KS * 64) void kbm_check_con(Dev d) {
+  if (d.ctrl->done) return;
+  __shared__ double lds[BM_KS * BM_NT * 256];
+  const size_t Bs = (size_t)d.Bs, MB = (size_t)d.M * Bs;
+  const int row0 = blockIdx.x * 16, col0 = blockIdx.y * BM_COLS;
+  const int e = threadIdx.x, t = e >> 8, g = (e & 255) >> 6, ll = e & 63;
+  const int row = row0 + (ll >> 4) + 4 * g, b = col0 + 16 * t + (ll & 15);
+  double4_t acc[BM_NT];
+  bm_tile(d.f_Ad, d.ldn, d.M, row0, 0, d.n, d.b_x + col0, Bs, acc);
+  const double ax = bm_reduce(acc, lds);
+  __syncthreads();
+  bm_tile(d.f_Ad, d.ldn, d.M, row0, 0, d.n, d.b_dx + col0, Bs, acc);
+  const double adx0 = bm_reduce(acc, lds);
+  if (row >= d.M) return;
+  const size_t o = row * Bs + b;
+  const double ei = d.Einv[row], z = d.b_z[o], l = d.b_l[o], u = d.b_u[o];
+  const bool uinf = u > QP_INFTY * QP_MIN_SCALING, linf = l < -QP_INFTY * QP_MIN_SCALING;
+  double v = d.b_dy[o];
+  if (uinf && linf) v = 0.0;
+  else if (uinf) v = fmin(v, 0.0);
+  else if (linf) v = fmax(v, 0.0);
+  const double adx = ei * adx0;
+  d.b_sm[0 * MB + o] = ei * (ax - z);
+  d.b_sm[1 * MB + o] = ei * ax;
+  d.b_sm[2 * MB + o] = ei * z;
+  d.b_sm[3 * MB + o] = v;
+  d.b_sm[4 * MB + o] = d.E[row] * v;
+  d.b_sm[5 * MB + o] = u * fmax(v, 0.0) + l * fmin(v, 0.0);
+  d.b_sm[6 * MB + o] = uinf ? -1.7e308 : adx;
+  d.b_sm[7 * MB + o] = linf ? 1.7e308 : adx;
+}
+
+// blocks [0, nbx): rows of Pbar against x, dx; blocks [nbx, 2 nbx): rows of Abar^T against y, projected dy
+__global__ __launch_bounds__(BM_KS * 64) void kbm_check_var(Dev d) {
+  if (d.ctrl->done) return;
+  __shared__ double lds[BM_KS * BM_NT * 256];
+  const size_t Bs = (size_t)d.Bs, NB = (size_t)d.n * Bs;
+  const int nbx = (d.n + 15) / 16;
+  const bool second = (int)blockIdx.x >= nbx;
+  const int row0 = ((int)blockIdx.x - (second ? nbx : 0)) * 16, col0 = blockIdx.y * BM_COLS;
+  const int e = threadIdx.x, t = e >> 8, g = (e & 255) >> 6, ll = e & 63;
+  const int row = row0 + (ll >> 4) + 4 * g, b = col0 + 16 * t + (ll & 15);
+  double4_t acc[BM_NT];
+  const double *A = second ? d.f_Atd : d.f_Pd;
+  const int ld = second ? d.ldm : d.ldn, K = second ? d.M : d.n;
+  const double *V0 = (second ? d.b_y : d.b_x) + col0;
+  const double *V1 = (second ? d.b_sm + 3 * (size_t)d.M * Bs : d.b_dx) + col0;
+  bm_tile(A, ld, d.n, row0, 0, K, V0, Bs, acc);
+  const double r0 = bm_reduce(acc, lds);
+  __syncthreads();
+  bm_tile(A, ld, d.n, row0, 0, K, V1, Bs, acc);
+  const double r1 = bm_reduce(acc, lds);
+  if (row >= d.n) return;
+  const size_t o = row * Bs + b;
+  d.b_sn[(second ? 2 : 0) * NB + o] = r0;
+  d.b_sn[(second ? 3 : 1) * NB + o] = d.Dinv[row] * r1;
+}
+
 // Stage 1 of the batched decision: grid (column tiles, KR row slices); every workgroup folds its
 // slice of rows for 64 columns and 17 quantities into b_part[tile][slice][q][64].
 constexpr int KR = 32;
@@ -2163,8 +2222,14 @@ int capture_chunk_b(miosqp_qp_engine *e, int iters, int ntiles, hipGraph_t *g, h
   HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
   hipLaunchKernelGGL(kb_tick, dim3(1), dim3(1), 0, e->stream, d, iters);
   for (int i = 0; i < iters; i++) launch_iteration_b(e, ntiles);
-  hipLaunchKernelGGL(kb_check_con, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
-  hipLaunchKernelGGL(kb_check_var, dim3(2 * ((d.n + 3) / 4), ntiles), dim3(256), 0, e->stream, d);
+  if (e->fold && e->bd_cfg == 0) {
+    const int ncol = ntiles * (64 / BM_COLS);
+    hipLaunchKernelGGL(kbm_check_con, dim3((d.M + 15) / 16, ncol), dim3(BM_KS * 64), 0, e->stream, d);
+    hipLaunchKernelGGL(kbm_check_var, dim3(2 * ((d.n + 15) / 16), ncol), dim3(BM_KS * 64), 0, e->stream, d);
+  } else {
+    hipLaunchKernelGGL(kb_check_con, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
+    hipLaunchKernelGGL(kb_check_var, dim3(2 * ((d.n + 3) / 4), ntiles), dim3(256), 0, e->stream, d);
+  }
   hipLaunchKernelGGL(kb_check_reduce, dim3(ntiles, KR), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_check_decide, dim3(ntiles), dim3(64), 0, e->stream, d);
   HIPCHK(hipStreamEndCapture(e->stream, g));
@@ -2487,6 +2552,10 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       miosqp::build_folded(f, e->fo);
       int rc = dupload(e, e->fo.rows, &d.f_rows);
       if (!rc) rc = dupload(e, e->fo.GmT, &d.f_GmT);
+      if (!rc) rc = dupload(e, e->fo.Ad, &d.f_Ad);
+      if (!rc) rc = dupload(e, e->fo.Atd, &d.f_Atd);
+      if (!rc) rc = dupload(e, e->fo.Pd, &d.f_Pd);
+      d.ldm = e->fo.ldm;
       if (rc) { miosqp_qp_cleanup(e); return rc; }
       d.ldf = e->fo.ldf;
       d.ldn = e->fo.ldn;
@@ -2525,6 +2594,9 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       }
       std::vector<double>().swap(e->fo.rows);
       std::vector<double>().swap(e->fo.GmT);
+      std::vector<double>().swap(e->fo.Ad);
+      std::vector<double>().swap(e->fo.Atd);
+      std::vector<double>().swap(e->fo.Pd);
     }
   }
   e->chunk = e->st.check_termination;

@@ -359,6 +359,21 @@ void build_folded(const Factor &f, Folded &o) {
   });
   for (int i = 0; i < n; i++)
     for (int j = 0; j < M; j++) o.GmT[(size_t)j * o.ldn + i] = o.rows[(size_t)i * o.ldf + j];
+  // dense Abar, Abar^T, Pbar
+  o.ldm = (M + 7) & ~7;
+  o.Ad.assign((size_t)(M > 0 ? M : 1) * o.ldn, 0.0);
+  o.Atd.assign((size_t)n * o.ldm, 0.0);
+  o.Pd.assign((size_t)n * o.ldn, 0.0);
+  const PCsr &C = f.panel_by_con;
+  for (int j = 0; j < M; j++)
+    for (int k = C.ptr[j]; k < C.ptr[j + 1]; k++)
+      if (f.A_val[k] != 0.0) {
+        o.Ad[(size_t)j * o.ldn + C.idx[k]] = f.A_val[k];
+        o.Atd[(size_t)C.idx[k] * o.ldm + j] = f.A_val[k];
+      }
+  for (int i = 0; i < n; i++)
+    for (int k = f.Pbar.ptr[i]; k < f.Pbar.ptr[i + 1]; k++)
+      if (f.Pbar.val[k] != 0.0) o.Pd[(size_t)i * o.ldn + f.Pbar.idx[k]] = f.Pbar.val[k];
 }
 
 }  // namespace miosqp

@@ -67,7 +67,11 @@ struct Factor {
 // of L21 (12 B/entry at ~70 % density vs 8 B/entry dense): both triangular sweeps then need ONE
 // row-parallel kernel each instead of two (panel + tail), halving the launches per iteration.
 struct Folded {
-  int n = 0, M = 0, ldf = 0, ldn = 0;
+  int n = 0, M = 0, ldf = 0, ldn = 0, ldm = 0;
+  // dense copies of the scaled matrices for the batched termination test (same tile kernels)
+  std::vector<double> Ad;   // M x ldn : Abar
+  std::vector<double> Atd;  // n x ldm : Abar^T
+  std::vector<double> Pd;   // n x ldn : Pbar (full symmetric)
   std::vector<double> rows;  // n x ldf row-major: row i = [ -G[i][0..M) | Linv[i][0..i) | 0.. ]
   std::vector<double> GmT;   // M x ldn row-major: GmT[j][i] = -G[i][j]
 };

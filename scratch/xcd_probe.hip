@@ -49,6 +49,45 @@ __global__ void k_barrier(int T, int iters, unsigned *cnt, double *slots, unsign
   if (threadIdx.x < T) sink[me * 64 + threadIdx.x] = acc;
 }
 
+// same-XCD team: 256 workgroups launched (one per CU through a 150 KB LDS request); those on XCD
+// `want` form a team (rank by arrival), the others exit.  Same publish + barrier + gather round.
+__global__ void k_team(int want, int iters, unsigned *reg, unsigned *cnt, double *slots, unsigned long long *tout,
+                       unsigned *tsize, double *sink, int payload) {
+  extern __shared__ double big[];
+  __shared__ int s_rank, s_T;
+  const unsigned x = xcc_id();
+  if (x != (unsigned)want) return;
+  if (threadIdx.x == 0) {
+    big[0] = 1.0;
+    s_rank = (int)__hip_atomic_fetch_add(reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the team size is known once every workgroup of the launch has started: wait for 32 (expected)
+    while (__hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 32u) {}
+    s_T = 32;
+  }
+  __syncthreads();
+  const int me = s_rank, T = s_T;
+  unsigned long long t0 = wall_clock64();
+  double acc = 0;
+  for (int it = 1; it <= iters; it++) {
+    // publish `payload` doubles per workgroup
+    for (int k = threadIdx.x; k < payload; k += blockDim.x)
+      __hip_atomic_store(&slots[me * payload + k], (double)(it + me + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)(it * T);
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < T * payload; k += blockDim.x)
+      acc += __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { tout[me] = wall_clock64() - t0; *tsize = T; }
+  sink[me * 1024 + threadIdx.x] = acc;
+}
+
 int main() {
   int ndev = 0;
   CK(hipGetDeviceCount(&ndev));
@@ -123,6 +162,24 @@ int main() {
       CK(hipMemcpy(tt.data(), tout, T * 8, hipMemcpyDeviceToHost));
       unsigned long long mx = *std::max_element(tt.begin(), tt.begin() + T);
       printf("  unmasked T=%d (spread over XCDs): %.3f us per round\n", T, mx * 10.0 / 1000.0 / iters);
+    }
+  }
+  // 5) same-XCD team of 32 workgroups
+  {
+    unsigned *reg, *cnt, *tsize; double *slots, *sink; unsigned long long *tout;
+    CK(hipMalloc(&reg, 4)); CK(hipMalloc(&cnt, 4)); CK(hipMalloc(&tsize, 4)); CK(hipMalloc(&slots, 32 * 64 * 8));
+    CK(hipMalloc(&sink, 64 * 1024 * 8)); CK(hipMalloc(&tout, 64 * 8));
+    CK(hipFuncSetAttribute((const void *)k_team, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    for (int payload : {1, 16, 56}) {
+      CK(hipMemset(reg, 0, 4)); CK(hipMemset(cnt, 0, 4));
+      const int iters = 2000;
+      hipLaunchKernelGGL(k_team, dim3(256), dim3(256), 150 * 1024, 0, 3, iters, reg, cnt, slots, tout, tsize, sink, payload);
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> tt(64);
+      CK(hipMemcpy(tt.data(), tout, 32 * 8, hipMemcpyDeviceToHost));
+      unsigned long long mx = *std::max_element(tt.begin(), tt.begin() + 32);
+      printf("  same-XCD team of 32, payload %d doubles/WG (gather %d): %.3f us per round\n", payload, 32 * payload,
+             mx * 10.0 / 1000.0 / iters);
     }
   }
   return 0;
