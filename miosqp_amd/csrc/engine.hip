@@ -1405,7 +1405,13 @@ __global__ __launch_bounds__(RG *KS * 64) void kbd_bwd(Dev d) {
 // covers k = k0 + 4*(l>>4) + s, so each lane reads its four A values as one 32-byte segment.
 // ------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int BM_KS = 8, BM_NT = 2, BM_COLS = 16 * BM_NT;
+#ifndef MIOSQP_BM_NT
+#define MIOSQP_BM_NT 2
+#endif
+#ifndef MIOSQP_BM_KS
+#define MIOSQP_BM_KS 8
+#endif
+constexpr int BM_KS = MIOSQP_BM_KS, BM_NT = MIOSQP_BM_NT, BM_COLS = 16 * BM_NT, BM_OUT = BM_NT * 256;
 
 __device__ __forceinline__ void bm_tile(const double *__restrict__ A, int ld, int nrows, int row0, int kbeg,
                                         int kend, const double *__restrict__ V, size_t Bs, double4_t (&acc)[BM_NT],
@@ -1490,10 +1496,11 @@ __device__ __forceinline__ double bm_reduce(const double4_t (&acc)[BM_NT], doubl
     for (int g = 0; g < 4; g++) lds[((w * BM_NT + t) * 4 + g) * 64 + lane] = acc[t][g];
   }
   __syncthreads();
-  const int e = threadIdx.x;  // BM_KS * 64 == BM_NT * 256 threads
+  const int e = threadIdx.x;  // threads e < BM_OUT own one output element each
+  if (e >= BM_OUT) return 0.0;
   double s = lds[e];
 #pragma unroll
-  for (int ww = 1; ww < BM_KS; ww++) s += lds[ww * (BM_NT * 256) + e];
+  for (int ww = 1; ww < BM_KS; ww++) s += lds[ww * BM_OUT + e];
   return s;
 }
 
@@ -1509,7 +1516,7 @@ __global__ __launch_bounds__(BM_KS * 64) void kbm_fwd(Dev d) {
   const double s = bm_reduce(acc, lds);
   const int e = threadIdx.x, t = e >> 8, g = (e & 255) >> 6, ll = e & 63;
   const int row = row0 + (ll >> 4) + 4 * g, b = col0 + 16 * t + (ll & 15);
-  if (row < d.n) d.b_ut[row * Bs + b] = d.d2inv[row] * (d.b_rx[row * Bs + b] + s);
+  if (e < BM_OUT && row < d.n) d.b_ut[row * Bs + b] = d.d2inv[row] * (d.b_rx[row * Bs + b] + s);
 }
 
 __global__ __launch_bounds__(BM_KS * 64) void kbm_bwd(Dev d) {
@@ -1526,7 +1533,7 @@ __global__ __launch_bounds__(BM_KS * 64) void kbm_bwd(Dev d) {
     bm_tile(d.LinvT, d.ld, d.n, row0, row0 + 1, d.n, d.b_ut + col0, Bs, acc);
     const double s = bm_reduce(acc, lds);
     const int row = row0 + (ll >> 4) + 4 * g;
-    if (row >= d.n) return;
+    if (e >= BM_OUT || row >= d.n) return;
     const size_t o = row * Bs + b;
     const double xt = d.b_ut[o] + s;
     d.b_xt[o] = xt;
@@ -1543,7 +1550,7 @@ __global__ __launch_bounds__(BM_KS * 64) void kbm_bwd(Dev d) {
   bm_tile(d.f_GmT, d.ldn, d.M, row0, 0, d.n, d.b_ut + col0, Bs, acc);
   const double s = bm_reduce(acc, lds);
   const int row = row0 + (ll >> 4) + 4 * g;
-  if (row >= d.M || d.c_done[b]) return;
+  if (e >= BM_OUT || row >= d.M || d.c_done[b]) return;
   const size_t o = row * Bs + b;
   const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha;
   const double zp = d.b_z[o], yp = d.b_y[o];
@@ -1588,7 +1595,7 @@ __global__ __launch_bounds__(BM_KS * 64) void kbm_check_con(Dev d) {
   __syncthreads();
   bm_tile(d.f_Ad, d.ldn, d.M, row0, 0, d.n, d.b_dx + col0, Bs, acc);
   const double adx0 = bm_reduce(acc, lds);
-  if (row >= d.M) return;
+  if (e >= BM_OUT || row >= d.M) return;
   const size_t o = row * Bs + b;
   const double ei = d.Einv[row], z = d.b_z[o], l = d.b_l[o], u = d.b_u[o];
   const bool uinf = u > QP_INFTY * QP_MIN_SCALING, linf = l < -QP_INFTY * QP_MIN_SCALING;
@@ -1627,7 +1634,7 @@ __global__ __launch_bounds__(BM_KS * 64) void kbm_check_var(Dev d) {
   __syncthreads();
   bm_tile(A, ld, d.n, row0, 0, K, V1, Bs, acc);
   const double r1 = bm_reduce(acc, lds);
-  if (row >= d.n) return;
+  if (e >= BM_OUT || row >= d.n) return;
   const size_t o = row * Bs + b;
   d.b_sn[(second ? 2 : 0) * NB + o] = r0;
   d.b_sn[(second ? 3 : 1) * NB + o] = d.Dinv[row] * r1;
