@@ -45,6 +45,39 @@ def pmc_traffic(kernel):
         return None
 
 
+def large_leg(seed, nodes=12):
+    """Extra leg, not part of `value`: BASELINE configs[4] (random_miqp n=5000 m=10000 p=2500, 1 % dense
+    A, fp64), where the single-node iteration is HBM-bandwidth-bound (317 MB algorithmic per iteration)."""
+    from miosqp_amd import bnb, dist, problems
+    cfg = problems.CONFIGS["cfg5"]
+    prob = problems.random_miqp(seed=seed, **cfg)
+    st = dict(problems.BNB_SETTINGS)
+    st["max_iter_bb"] = 10 ** 9
+    model = bnb.MIOSQP()
+    t0 = time.time()
+    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"], prob["i_u"], st,
+                dict(problems.QP_SETTINGS))
+    setup_s = time.time() - t0
+    eng = model.work.solver
+    srch = dist.ShardedSearch(model)
+    srch.step(1)
+    eng.loop_stats(reset=True)
+    n0, i0 = srch.nodes, srch.iters
+    t0 = time.perf_counter()
+    for _ in range(nodes):
+        srch.step(1)
+    dt = time.perf_counter() - t0
+    ms, it = eng.loop_stats()
+    fs = eng.factor_stats()
+    gbs = fs["bytes_per_iter"] * it / max(1e-9, ms) * 1e-6
+    return dict(workload="random_miqp n=%d m=%d p=%d density %.2f, node-at-a-time" %
+                         (cfg["n"], cfg["m"], cfg["p"], cfg["density"]),
+                iters_per_s=round((srch.iters - i0) / dt, 1), nodes_per_s=round((srch.nodes - n0) / dt, 2),
+                nnz_L=fs["nnz_L"], setup_s=round(setup_s, 2), bytes_per_iter=fs["bytes_per_iter"],
+                usec_per_iter=round(1e3 * ms / max(1, it), 2), achieved_gbs=round(gbs, 1),
+                frac=round(gbs / HBM_PEAK_GBS, 4), factor_form="L (4 launches/iteration)")
+
+
 def cpu_baseline(prob, budget_s):
     """The CPU oracle ("port": own restatement, NOT the real OSQP which is absent) on the same tree,
     one thread, bounded to about `budget_s` seconds."""
@@ -79,6 +112,8 @@ def main():
     ap.add_argument("--batch-width", type=int, default=256,
                     help="extra leg: leaves per batched wave (BASELINE configs[2]); 0 = skip")
     ap.add_argument("--batch-waves", type=int, default=12)
+    ap.add_argument("--no-large-leg", action="store_true",
+                    help="skip the extra BASELINE configs[4] leg (n=5000, bandwidth-bound single-node ADMM)")
     args = ap.parse_args()
 
     import torch
@@ -226,6 +261,8 @@ def main():
                 bk.append(dict(kernel=nm, usec=round(us, 2), bytes=by, gbs=round(by / us * 1e-3, 1)))
             batched["kernels"] = bk
             out["batched"] = batched
+        if world == 1 and not args.no_large_leg and args.config == "cfg2":
+            out["config5"] = large_leg(args.seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
         print(json.dumps(out))

@@ -459,3 +459,50 @@ def test_setup_rejects_bad_input():
                         np.ones(3), scaling=0)
     with pytest.raises(ValueError):
         qp.OSQP().setup(P, np.zeros(3), spa.csc_matrix(np.eye(3)), -np.ones(3), np.ones(3), adaptive_rho=True)
+
+
+@pytest.mark.parametrize("fold,resident", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("max_iter,check", [(60, 25), (50, 0), (30, 7), (25, 25), (3, 1)])
+def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, max_iter, check):
+    """MAX_ITER_REACHED, a tail chunk shorter than the cadence, cadence 1, and the test switched off:
+    status, iteration count and iterates equal the oracle's in every engine form."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(40, 60, 10, seed=21)
+    A, l, u = problems.extended(pr)
+    kw = dict(problems.QP_SETTINGS, max_iter=max_iter, check_termination=check, eps_abs=1e-9, eps_rel=1e-9)
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, **kw)
+    o.setup(pr["P"], pr["q"], A, l, u, **kw)
+    x0, y0 = np.full(40, 0.3), np.zeros(A.shape[0])
+    g.warm_start(x=x0, y=y0)
+    o.warm_start(x=x0, y=y0)
+    rg, ro = g.solve(), o.solve()
+    assert ro.info.status_val == -2 and ro.info.iter == max_iter
+    assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
+    assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL
+    # loose tolerances: converges at the first test that passes; same iteration as the oracle
+    kw2 = dict(problems.QP_SETTINGS, max_iter=4000, check_termination=max(check, 1))
+    g2, o2 = qp.OSQP(), oracle_mod.OSQP()
+    g2.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, **kw2)
+    o2.setup(pr["P"], pr["q"], A, l, u, **kw2)
+    g2.warm_start(x=x0, y=y0)
+    o2.warm_start(x=x0, y=y0)
+    rg2, ro2 = g2.solve(), o2.solve()
+    assert ro2.info.status_val == 1
+    assert (rg2.info.status_val, rg2.info.iter) == (ro2.info.status_val, ro2.info.iter)
+    assert rel(rg2.x, ro2.x) <= SOL_TOL and rel(rg2.y, ro2.y) <= SOL_TOL
+
+
+def test_cold_start_setting(oracle_mod):
+    """warm_start=False: every solve restarts from zero (x1-x15 'cold start'), as the oracle does."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(30, 40, 8, seed=22)
+    A, l, u = problems.extended(pr)
+    kw = dict(problems.QP_SETTINGS, warm_start=False)
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **kw)
+    o.setup(pr["P"], pr["q"], A, l, u, **kw)
+    a, b = g.solve(), o.solve()
+    a2, b2 = g.solve(), o.solve()
+    assert (a.info.iter, a2.info.iter) == (b.info.iter, b2.info.iter) and a.info.iter == a2.info.iter
+    assert rel(a2.x, b2.x) <= SOL_TOL
