@@ -63,7 +63,9 @@ typedef struct miosqp_qp_settings {
                                 (2 kernels/iteration; auto picks it for panels denser than 30 %) */
   int32_t resident;          /* -1 auto, 0 off, 1 on: whole solve in ONE LDS-resident workgroup when the
                                 product-form factor and all iterates fit in 160 KB of LDS */
-  int32_t reserved[4];
+  int32_t setup_on_device;   /* -1 auto (n >= 1024), 0 host, 1 device: dense LDL^T of the reduced Hessian and
+                                the inverse of its triangular factor computed on the GPU at setup */
+  int32_t reserved[3];
 } miosqp_qp_settings;
 
 /* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus
@@ -159,7 +161,8 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
 
 /* sizes of the factor: out[0]=nnz(L) strict (panel + tail), out[1]=nnz panel, out[2]=tail order,
  * out[3]=algorithmic bytes per ADMM iteration (SURVEY.md sec. 8d formula), out[4..6] threads per
- * row of the panel/tail kernels, out[7] bit 0 = product-form factor in use, bit 1 = LDS-resident solver in use */
+ * row of the panel/tail kernels, out[7] bit 0 = product-form factor in use, bit 1 = LDS-resident solver in use,
+ * bit 2 = dense setup stages ran on the device */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
 
 /* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's

@@ -1,0 +1,257 @@
+// Device side of the one-time setup: the dense part of the KKT
+// factorisation -- blocked LDL^T of the reduced Hessian S = Pbar + sigma I + rho Abar^T Abar, the
+// inverse of its unit-lower factor, and the transpose -- on the GPU.  This is the one dense
+// contraction of the whole path (n^3/3 flops each; 4e10 at config 5); everything is 64 x 64 tiles
+// staged in LDS, fp64 vector FMA, fixed summation order.
+//
+//   ks_diag    factor one 64 x 64 diagonal block in LDS (right-looking, unblocked)
+//   ks_panel   rows below it: L[i, block] and W = L * diag(d)
+//   ks_update  trailing update  S[i,j] -= W[i,:] . L[j,:]   over lower-triangular tiles
+//   ks_inv     block row I of X = L^-1:  X[I,J] = L_II^-1 ( [I == J] - sum_{K=J}^{I-1} L[I,K] X[K,J] )
+//   ks_out     strict lower part of X -> Linv, its transpose -> LinvT
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+namespace {
+
+constexpr int NB = 64, LP = NB + 1;  // tile size, padded LDS row
+
+#define SCK(call)                                                                           \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      fprintf(stderr, "[miosqp setup] %s: %s\n", #call, hipGetErrorString(e__));            \
+      rc = -2;                                                                              \
+      goto done;                                                                            \
+    }                                                                                       \
+  } while (0)
+
+__global__ __launch_bounds__(256) void ks_diag(double *S, int ld, int jb, int w, double *d, int *flag) {
+  __shared__ double A[NB][LP];
+  __shared__ double col[NB];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, j = e % NB;
+    A[i][j] = (i < w && j <= i) ? S[(size_t)(jb + i) * ld + jb + j] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < w; j++) {
+    const double dj = A[j][j];
+    if (!(dj > 0.0)) {
+      if (tid == 0) *flag = 1;
+      return;  // uniform: every thread reads the same A[j][j]
+    }
+    if (tid > j && tid < w) {
+      const double l = A[tid][j] / dj;
+      col[tid] = l;
+      A[tid][j] = l;
+    }
+    __syncthreads();
+    // A[i][k] -= l_i d_j l_k for j < k <= i < w
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int i = e / NB, k = e % NB;
+      if (k > j && k <= i && i < w) A[i][k] -= col[i] * dj * col[k];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, j = e % NB;
+    if (i < w && j < i) S[(size_t)(jb + i) * ld + jb + j] = A[i][j];
+  }
+  if (tid < w) d[jb + tid] = A[tid][tid];
+}
+
+// one wave per 64 rows: thread r owns row je + 64 b + r of the panel
+__global__ __launch_bounds__(64) void ks_panel(double *S, int ld, int n, int jb, int w, const double *d, double *W) {
+  __shared__ double P[NB][LP];   // panel rows
+  __shared__ double DL[NB][LP];  // DL[j][k] = d_k * L_jj[j][k]
+  __shared__ double dd[NB];
+  const int r = threadIdx.x, je = jb + w;
+  const int i0 = je + blockIdx.x * NB, i = i0 + r;
+  for (int e = r; e < NB * NB; e += 64) {
+    const int j = e / NB, k = e % NB;
+    DL[j][k] = (j < w && k < j) ? S[(size_t)(jb + j) * ld + jb + k] * d[jb + k] : 0.0;
+    const int ii = i0 + j;
+    P[j][k] = (ii < n && k < w) ? S[(size_t)ii * ld + jb + k] : 0.0;
+  }
+  if (r < w) dd[r] = d[jb + r];
+  __syncthreads();
+  for (int j = 0; j < w; j++) {
+    double v = P[r][j];
+    for (int k = 0; k < j; k++) v -= P[r][k] * DL[j][k];
+    P[r][j] = v / dd[j];
+  }
+  __syncthreads();
+  for (int e = r; e < NB * NB; e += 64) {
+    const int j = e / NB, k = e % NB;
+    const int ii = i0 + j;
+    if (ii < n && k < w) {
+      S[(size_t)ii * ld + jb + k] = P[j][k];
+      W[(size_t)ii * NB + k] = P[j][k] * dd[k];
+    }
+  }
+  (void)i;
+}
+
+// 64 x 64 tile (ti, tj), tj <= ti, of the trailing matrix: S -= W L^T over the current 64 columns
+__global__ __launch_bounds__(256) void ks_update(double *S, int ld, int n, int jb, int w, const double *W) {
+  const int je = jb + w;
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (tj > ti) return;
+  __shared__ double Wt[NB][LP], Lt[NB][LP];
+  const int i0 = je + ti * NB, j0 = je + tj * NB;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int a = e / NB, k = e % NB;
+    Wt[a][k] = (i0 + a < n && k < w) ? W[(size_t)(i0 + a) * NB + k] : 0.0;
+    Lt[a][k] = (j0 + a < n && k < w) ? S[(size_t)(j0 + a) * ld + jb + k] : 0.0;
+  }
+  __syncthreads();
+  double acc[4][4] = {};
+  for (int k = 0; k < NB; k++) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      a[u] = Wt[ty + 16 * u][k];
+      b[u] = Lt[tx + 16 * u][k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int i = i0 + ty + 16 * u, j = j0 + tx + 16 * v;
+      if (i < n && j <= i) S[(size_t)i * ld + j] -= acc[u][v];
+    }
+}
+
+// block row I of X = L^-1 (X holds explicit ones on its diagonal while it is being built)
+__global__ __launch_bounds__(256) void ks_inv(const double *L, double *X, int ld, int n, int I) {
+  const int J = blockIdx.x;  // column block, J <= I
+  __shared__ double At[NB][LP], Bt[NB][LP];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int i0 = I * NB, j0 = J * NB;
+  double acc[4][4] = {};
+  for (int K = J; K < I; K++) {
+    const int k0 = K * NB;
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int a = e / NB, k = e % NB;
+      At[a][k] = (i0 + a < n) ? L[(size_t)(i0 + a) * ld + k0 + k] : 0.0;                  // L[I,K]
+      Bt[a][k] = (k0 + a < n && j0 + k < n) ? X[(size_t)(k0 + a) * ld + j0 + k] : 0.0;   // X[K,J]
+    }
+    __syncthreads();
+    for (int k = 0; k < NB; k++) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        a[u] = At[ty + 16 * u][k];
+        b[u] = Bt[k][tx + 16 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+    }
+  }
+  __syncthreads();
+  // R = [I == J] - acc into Bt, L_II (unit lower) into At, then one thread per column substitutes
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int r = ty + 16 * u, c = tx + 16 * v;
+      Bt[r][c] = ((I == J && r == c) ? 1.0 : 0.0) - acc[u][v];
+    }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int a = e / NB, k = e % NB;
+    At[a][k] = (i0 + a < n && k < a) ? L[(size_t)(i0 + a) * ld + i0 + k] : 0.0;
+  }
+  __syncthreads();
+  if (tid < NB) {
+    const int c = tid;
+    for (int r = 1; r < NB; r++) {
+      double v = Bt[r][c];
+      for (int k = 0; k < r; k++) v -= At[r][k] * Bt[k][c];
+      Bt[r][c] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    if (i0 + r < n && j0 + c < n) X[(size_t)(i0 + r) * ld + j0 + c] = (I == J && c > r) ? 0.0 : Bt[r][c];
+  }
+}
+
+// Linv = strict lower part of X, LinvT = its transpose (64 x 64 tiles through LDS)
+__global__ __launch_bounds__(256) void ks_out(const double *X, double *Linv, double *LinvT, int ld, int n) {
+  __shared__ double T[NB][LP];
+  const int i0 = blockIdx.x * NB, j0 = blockIdx.y * NB, tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    const int i = i0 + r, j = j0 + c;
+    const double v = (i < n && j < i) ? X[(size_t)i * ld + j] : 0.0;
+    T[r][c] = v;
+    if (i < n && j < n) Linv[(size_t)i * ld + j] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;  // LinvT[j0 + r][i0 + c] = X[i0 + c][j0 + r]
+    if (j0 + r < n && i0 + c < n) LinvT[(size_t)(j0 + r) * ld + i0 + c] = T[c][r];
+  }
+}
+
+}  // namespace
+
+// matches miosqp::DenseLdlInv (factor.hpp)
+int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double *Linv, double *LinvT, void *ctx) {
+  hipStream_t st = (hipStream_t)ctx;
+  double *dS = nullptr, *dX = nullptr, *dT = nullptr, *dW = nullptr, *dd = nullptr;
+  int *dflag = nullptr, hflag = 0, rc = 0;
+  const size_t mat = (size_t)n * ld * sizeof(double);
+  const int nt = (n + NB - 1) / NB;
+  SCK(hipMalloc((void **)&dS, mat));
+  SCK(hipMalloc((void **)&dX, mat));
+  SCK(hipMalloc((void **)&dT, mat));
+  SCK(hipMalloc((void **)&dW, (size_t)n * NB * sizeof(double)));
+  SCK(hipMalloc((void **)&dd, (size_t)n * sizeof(double)));
+  SCK(hipMalloc((void **)&dflag, sizeof(int)));
+  SCK(hipMemcpyAsync(dS, S, mat, hipMemcpyHostToDevice, st));
+  SCK(hipMemsetAsync(dX, 0, mat, st));
+  SCK(hipMemsetAsync(dT, 0, mat, st));
+  SCK(hipMemsetAsync(dflag, 0, sizeof(int), st));
+  for (int jb = 0; jb < n; jb += NB) {
+    const int w = n - jb < NB ? n - jb : NB, je = jb + w;
+    hipLaunchKernelGGL(ks_diag, dim3(1), dim3(256), 0, st, dS, ld, jb, w, dd, dflag);
+    if (je >= n) break;
+    const int rt = (n - je + NB - 1) / NB;
+    hipLaunchKernelGGL(ks_panel, dim3(rt), dim3(64), 0, st, dS, ld, n, jb, w, dd, dW);
+    hipLaunchKernelGGL(ks_update, dim3(rt, rt), dim3(256), 0, st, dS, ld, n, jb, w, dW);
+  }
+  SCK(hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+  SCK(hipStreamSynchronize(st));
+  if (hflag) {
+    rc = 1;
+    goto done;
+  }
+  for (int I = 0; I < nt; I++) hipLaunchKernelGGL(ks_inv, dim3(I + 1), dim3(256), 0, st, dS, dX, ld, n, I);
+  // dS is free now: reuse it for Linv
+  hipLaunchKernelGGL(ks_out, dim3(nt, nt), dim3(256), 0, st, dX, dS, dT, ld, n);
+  SCK(hipMemcpyAsync(d, dd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  SCK(hipMemcpyAsync(Linv, dS, mat, hipMemcpyDeviceToHost, st));
+  SCK(hipMemcpyAsync(LinvT, dT, mat, hipMemcpyDeviceToHost, st));
+  SCK(hipStreamSynchronize(st));
+done:
+  hipFree(dS);
+  hipFree(dX);
+  hipFree(dT);
+  hipFree(dW);
+  hipFree(dd);
+  hipFree(dflag);
+  return rc;
+}

@@ -33,6 +33,9 @@
 #define QP_MIN_SCALING 1e-4
 #define QP_DIVISION_TOL (1.0 / QP_INFTY)
 
+// dense_setup.hip: dense LDL^T + triangular inverse on the device (miosqp::DenseLdlInv)
+int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double *Linv, double *LinvT, void *ctx);
+
 namespace {
 
 thread_local std::string g_err;
@@ -1978,6 +1981,7 @@ struct miosqp_qp_engine {
   double *d_in = nullptr;
   bool have_int = false;
   bool fold = false;
+  bool setup_on_device = false;
   bool res_pending = false, loop_pending = false;
   Ctrl *h_ctrl2 = nullptr;  // two pinned slots for the pipelined chunk loop
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
@@ -2386,6 +2390,7 @@ int miosqp_qp_default_settings(miosqp_qp_settings *s) {
   s->max_batch = 1;
   s->fold = -1;
   s->resident = -1;
+  s->setup_on_device = -1;
   return 0;
 }
 
@@ -2467,7 +2472,12 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     e->st.check_termination = e->st.max_iter;
   miosqp::scale_problem(n, M, Pp, Pi, Px, Ap, Ai, Ax, q, s->scaling, e->sc);
   std::string err;
-  if (!miosqp::build_factor(e->sc, Pp, Pi, Px, s->rho, s->sigma, e->fa, err)) {
+  // dense part of the factorisation on the device for large problems
+  int on_dev = s->setup_on_device;
+  if (on_dev < 0) on_dev = n >= 1024 ? 1 : 0;
+  e->setup_on_device = on_dev != 0;
+  if (!miosqp::build_factor(e->sc, Pp, Pi, Px, s->rho, s->sigma, e->fa, err,
+                            on_dev ? miosqp_device_ldl_inverse : nullptr, nullptr)) {
     g_err = err;
     delete e;
     return MIOSQP_EFACTOR;
@@ -2807,7 +2817,7 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[1] = e->fa.nnz_panel;
   out[2] = e->n;
   out[3] = (int64_t)b[4];
-  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0);
+  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0);
   return 0;
 }
 

@@ -109,6 +109,7 @@ void pack_rows(int rows, int cols, std::vector<std::vector<Triplet>> &r, PCsr &o
 void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
                    const int32_t *Ap, const int32_t *Ai, const double *Ax, const double *q,
                    int passes, Scaled &s) {
+  StageTimer tm;
   s.n = n;
   s.M = M;
   s.Pp.assign(n + 1, 0);
@@ -163,6 +164,7 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
     for (double &v : s.q) v *= ct;
     s.c *= ct;
   }
+  tm.lap("copy + Ruiz equilibration");
   s.Dinv.resize(n);
   s.Einv.resize(M);
   for (int j = 0; j < n; j++) s.Dinv[j] = 1.0 / s.D[j];
@@ -171,7 +173,8 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
 }
 
 bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
-                  const double *Px_raw, double rho, double sigma, Factor &f, std::string &err) {
+                  const double *Px_raw, double rho, double sigma, Factor &f, std::string &err,
+                  DenseLdlInv accel, void *accel_ctx) {
   const int n = s.n, M = s.M;
   StageTimer tm;
   f.n = n;
@@ -197,25 +200,44 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
     f.nnz_panel = f.panel_by_var.nnz;
   }
   tm.lap("panel rows");
-  // ---- symmetric matrices by row ----------------------------------------------------------
+  // ---- symmetric matrices by row (counting transpose of the upper triangle; columns ascend) ----
   {
-    std::vector<std::vector<Triplet>> rows(n);
-    for (int j = 0; j < n; j++)
-      for (int p = s.Pp[j]; p < s.Pp[j + 1]; p++) {
-        int i = s.Pi[p];
-        rows[i].push_back({j, s.Px[p], 0});
-        if (i != j) rows[j].push_back({i, s.Px[p], 0});
+    auto sym_rows = [&](const int *Pp_, const int *Pi_, const double *Px_, bool upper_only_input, PCsr &out) {
+      out.rows = out.cols = n;
+      std::vector<int> cnt(n, 0);
+      for (int j = 0; j < n; j++)
+        for (int p = Pp_[j]; p < Pp_[j + 1]; p++) {
+          const int i = Pi_[p];
+          if (i > j) continue;  // only the upper triangle is read
+          cnt[i]++;
+          if (i != j) cnt[j]++;
+        }
+      (void)upper_only_input;
+      out.ptr.assign(n + 1, 0);
+      out.nnz = 0;
+      for (int i = 0; i < n; i++) {
+        out.nnz += cnt[i];
+        out.ptr[i + 1] = out.ptr[i] + ((cnt[i] + 1) & ~1);
       }
-    pack_rows(n, n, rows, f.Pbar, nullptr);
-    for (auto &r : rows) r.clear();
-    for (int j = 0; j < n; j++)
-      for (int p = Pp_raw[j]; p < Pp_raw[j + 1]; p++) {
-        int i = Pi_raw[p];
-        if (i > j) continue;
-        rows[i].push_back({j, Px_raw[p], 0});
-        if (i != j) rows[j].push_back({i, Px_raw[p], 0});
-      }
-    pack_rows(n, n, rows, f.Praw, nullptr);
+      out.idx.assign(out.ptr[n], 0);
+      out.val.assign(out.ptr[n], 0.0);
+      std::vector<int> cur(out.ptr.begin(), out.ptr.end() - 1);
+      for (int j = 0; j < n; j++)
+        for (int p = Pp_[j]; p < Pp_[j + 1]; p++) {
+          const int i = Pi_[p];
+          if (i > j) continue;
+          out.idx[cur[i]] = j;
+          out.val[cur[i]++] = Px_[p];
+          if (i != j) {
+            out.idx[cur[j]] = i;
+            out.val[cur[j]++] = Px_[p];
+          }
+        }
+      for (int i = 0; i < n; i++)
+        if (cur[i] < out.ptr[i + 1]) out.idx[cur[i]] = cnt[i] ? out.idx[cur[i] - 1] : 0;  // zero-valued pad
+    };
+    sym_rows(s.Pp.data(), s.Pi.data(), s.Px.data(), true, f.Pbar);
+    sym_rows(Pp_raw, Pi_raw, Px_raw, false, f.Praw);
   }
   tm.lap("P rows");
   // ---- Schur complement S = Pbar + sigma I + rho Abar^T Abar (dense, lower, row-major) -----
@@ -243,6 +265,25 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
     // padding entries carry value 0, so a repeated last column adds nothing
   }
   tm.lap("Schur complement");
+  if (accel) {
+    // dense LDL^T, triangular inverse and transpose on the device
+    std::vector<double> dd(n);
+    f.Linv.assign((size_t)n * ld, 0.0);
+    f.LinvT.assign((size_t)n * ld, 0.0);
+    const int rc = accel(n, ld, S.data(), dd.data(), f.Linv.data(), f.LinvT.data(), accel_ctx);
+    if (rc == 1) {
+      err = "KKT factorisation: non-positive pivot in the reduced Hessian (P not PSD?)";
+      return false;
+    }
+    if (rc == 0) {
+      f.d2inv.resize(n);
+      for (int j = 0; j < n; j++) f.d2inv[j] = 1.0 / dd[j];
+      f.nnz_tail = (int64_t)n * (n - 1) / 2;
+      tm.lap("device LDL^T + inverse");
+      return true;
+    }
+    // device error: fall through to the host path
+  }
   // ---- blocked right-looking LDL^T of S (in place: strict lower = L22, diag = D22) ------
   std::vector<double> d(n);
   const int nb = 64;

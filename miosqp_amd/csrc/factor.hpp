@@ -82,8 +82,15 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
                    const int32_t *Ap, const int32_t *Ai, const double *Ax, const double *q,
                    int passes, Scaled &out);
 
+// Optional accelerator for the dense part of the setup: given the
+// reduced Hessian S (n x ld row-major, lower triangle valid) it must produce d (D22), Linv
+// (strict lower of L22^-1, n x ld) and LinvT (its transpose); returns 0 on success, 1 when a
+// pivot is not positive, <0 on a device error.  The engine passes its HIP implementation here.
+typedef int (*DenseLdlInv)(int n, int ld, const double *S, double *d, double *Linv, double *LinvT, void *ctx);
+
 // Builds the factor; returns false with `err` set when D22 loses positivity.
 bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
-                  const double *Px_raw, double rho, double sigma, Factor &f, std::string &err);
+                  const double *Px_raw, double rho, double sigma, Factor &f, std::string &err,
+                  DenseLdlInv accel = nullptr, void *accel_ctx = nullptr);
 
 }  // namespace miosqp

@@ -506,3 +506,31 @@ def test_cold_start_setting(oracle_mod):
     a2, b2 = g.solve(), o.solve()
     assert (a.info.iter, a2.info.iter) == (b.info.iter, b2.info.iter) and a.info.iter == a2.info.iter
     assert rel(a2.x, b2.x) <= SOL_TOL
+
+
+@pytest.mark.parametrize("n,m,p,seed", [(50, 100, 10, 1), (130, 260, 65, 2), (200, 50, 100, 3), (257, 40, 20, 4)])
+def test_device_setup_matches_host_setup(oracle_mod, n, m, p, seed):
+    """setup_on_device=1 (dense LDL^T + triangular inverse on the GPU) gives
+    the same iterates as the host setup and as the oracle; block sizes around the 64-tile edges."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    A, l, u = problems.extended(pr)
+    o = oracle_mod.OSQP()
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    rng = np.random.RandomState(seed)
+    x0, y0 = rng.randn(n), rng.randn(A.shape[0])
+    outs = []
+    for dev in (0, 1):
+        g = qp.OSQP()
+        g.setup(pr["P"], pr["q"], A, l, u, setup_on_device=dev, resident=0, **problems.QP_SETTINGS)
+        assert g.factor_stats()["setup_on_device"] == bool(dev)
+        g.warm_start(x=x0, y=y0)
+        outs.append(g.debug_iterate(40))
+    o.warm_start(x=x0, y=y0)
+    o.iterate(40)
+    ref = o.iterates()
+    for got in outs:
+        for a, b in zip(got, ref):
+            assert rel(a, b) <= ITER_TOL
+    for a, b in zip(outs[0], outs[1]):
+        assert rel(a, b) <= 1e-11
