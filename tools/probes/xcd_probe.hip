@@ -39,7 +39,7 @@ __global__ void k_barrier(int T, int iters, unsigned *cnt, double *slots, unsign
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = (unsigned)(it * T);
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+      { unsigned sp = 0; while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++sp < 2000000u) {} }
     }
     __syncthreads();
     if (threadIdx.x < T) acc += __hip_atomic_load(&slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -61,7 +61,7 @@ __global__ void k_team(int want, int iters, unsigned *reg, unsigned *cnt, double
     big[0] = 1.0;
     s_rank = (int)__hip_atomic_fetch_add(reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the team size is known once every workgroup of the launch has started: wait for 32 (expected)
-    while (__hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 32u) {}
+    { unsigned sp = 0; while (__hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 32u && ++sp < 2000000u) {} }
     s_T = 32;
   }
   __syncthreads();
@@ -77,7 +77,7 @@ __global__ void k_team(int want, int iters, unsigned *reg, unsigned *cnt, double
     if (threadIdx.x == 0) {
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = (unsigned)(it * T);
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {}
+      { unsigned sp = 0; while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++sp < 2000000u) {} }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < T * payload; k += blockDim.x)
@@ -85,6 +85,64 @@ __global__ void k_team(int want, int iters, unsigned *reg, unsigned *cnt, double
     __syncthreads();
   }
   if (threadIdx.x == 0) { tout[me] = wall_clock64() - t0; *tsize = T; }
+  sink[me * 1024 + threadIdx.x] = acc;
+}
+
+// same-XCD team, L2-local synchronisation: counter RMWs at WORKGROUP scope (no sc bits: performed in
+// this XCD's L2), payload by plain stores (write-through to the L2) and non-temporal loads (bypass L1,
+// L2-served).  Only meaningful because every member verified the same XCC id.
+__global__ void k_team_l2(int want, int iters, unsigned *reg, unsigned *cnt, double *slots, unsigned long long *tout,
+                          double *sink, int payload, unsigned *bad) {
+  extern __shared__ double big[];
+  __shared__ int s_rank, s_fail;
+  const unsigned x = xcc_id();
+  if (x != (unsigned)want) return;
+  if (threadIdx.x == 0) {
+    big[0] = 1.0;
+    s_fail = 0;
+    s_rank = (int)__hip_atomic_fetch_add(reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 32u && ++spins < 2000000u) {}
+    if (spins >= 2000000u) s_fail = 1;
+  }
+  __syncthreads();
+  const int me = s_rank, T = 32;
+  unsigned long long t0 = wall_clock64();
+  double acc = 0;
+  unsigned nbad = 0;
+  for (int it = 1; it <= iters; it++) {
+    for (int k = threadIdx.x; k < payload; k += blockDim.x) slots[me * payload + k] = (double)(it * 1000 + me);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned target = (unsigned)(it * T);
+      unsigned spins = 0;
+      while (__builtin_nontemporal_load(cnt) < target && ++spins < 200000u) {}
+      if (spins >= 200000u) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) break;
+    for (int k = threadIdx.x; k < T * payload; k += blockDim.x) {
+      const double v = __builtin_nontemporal_load(&slots[k]);
+      acc += v;
+      if (v != (double)(it * 1000 + k / payload)) nbad++;
+    }
+    __syncthreads();
+    // second barrier so that nobody overwrites slots while others still read (ping-pong would avoid it)
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned target = (unsigned)(it * T);
+      unsigned spins = 0;
+      while (__builtin_nontemporal_load(cnt + 1) < target && ++spins < 200000u) {}
+      if (spins >= 200000u) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) break;
+  }
+  if (threadIdx.x == 0) tout[me] = wall_clock64() - t0;
+  if (s_fail && threadIdx.x == 0) atomicAdd(bad, 1000000u);
+  if (nbad) atomicAdd(bad, nbad);
   sink[me * 1024 + threadIdx.x] = acc;
 }
 
@@ -180,6 +238,27 @@ int main() {
       unsigned long long mx = *std::max_element(tt.begin(), tt.begin() + 32);
       printf("  same-XCD team of 32, payload %d doubles/WG (gather %d): %.3f us per round\n", payload, 32 * payload,
              mx * 10.0 / 1000.0 / iters);
+    }
+  }
+  // 6) same-XCD team with L2-local synchronisation (two barriers per round, payload verified)
+  {
+    unsigned *reg, *cnt, *bad; double *slots, *sink; unsigned long long *tout;
+    CK(hipMalloc(&reg, 4)); CK(hipMalloc(&cnt, 8)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&slots, 32 * 64 * 8));
+    CK(hipMalloc(&sink, 64 * 1024 * 8)); CK(hipMalloc(&tout, 64 * 8));
+    CK(hipFuncSetAttribute((const void *)k_team_l2, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    for (int payload : {1, 16, 56}) {
+      CK(hipMemset(reg, 0, 4)); CK(hipMemset(cnt, 0, 8)); CK(hipMemset(bad, 0, 4));
+      const int iters = 2000;
+      hipLaunchKernelGGL(k_team_l2, dim3(256), dim3(256), 150 * 1024, 0, 5, iters, reg, cnt, slots, tout, sink, payload, bad);
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) { printf("k_team_l2 failed: %s\n", hipGetErrorString(e)); break; }
+      std::vector<unsigned long long> tt(64);
+      unsigned hb = 0;
+      CK(hipMemcpy(tt.data(), tout, 32 * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
+      unsigned long long mx = *std::max_element(tt.begin(), tt.begin() + 32);
+      printf("  same-XCD L2-local team, payload %d doubles/WG: %.3f us per round (2 barriers), stale reads %u\n", payload,
+             mx * 10.0 / 1000.0 / iters, hb);
     }
   }
   return 0;
