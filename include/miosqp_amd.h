@@ -184,6 +184,17 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters,
                               int64_t *node_iters, int32_t reset);
 
+/* debug counters: which = 0 -> number of wave compactions solve_batch has performed */
+int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which);
+
+/* debug: per-workgroup (start, end) stamps (100 MHz wall clock) of ONE launch of a product-form
+ * kernel (which: 0 forward, 1 backward); out holds 2 * max_blocks values */
+int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
+                             int32_t *nblocks);
+
+/* debug: shader cycles and 100 MHz ticks recorded by the last LDS-resident launch */
+int miosqp_qp_debug_clock(miosqp_qp_engine *e, double *cycles, double *ticks);
+
 #ifdef __cplusplus
 }
 #endif

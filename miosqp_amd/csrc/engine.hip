@@ -110,6 +110,8 @@ struct Dev {
   double *b_xi, *b_xis;     // rounded candidates (node digest), unscaled / scaled
   double *b_part;           // partial reductions of the batched termination test
   int *c_intinf, *c_nextvar;
+  int *c_node;   // column position -> node of the wave (columns are swapped when the wave is compacted)
+  int *c_pairs;  // swap list of the current compaction
   double *c_hviol, *c_hobj;
   double *b_raw;            // node-major staging in:  l[B][M] | u[B][M] | x0[B][n] | y0[B][M]
   double *b_out;            // node-major staging out: x[B][n] | y[B][M]
@@ -1742,6 +1744,7 @@ __global__ void kb_reset(Dev d, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < d.Bs) {
     d.c_done[b] = b >= B;
+    d.c_node[b] = b;
     d.c_status[b] = MIOSQP_QP_UNSOLVED;
     d.c_iter[b] = 0;
     d.c_pri[b] = d.c_dua[b] = d.c_obj[b] = 0.0;
@@ -1791,6 +1794,32 @@ __global__ __launch_bounds__(256) void kb_warm_z(Dev d) {
   d.b_wh[o] = z - d.rho_inv * d.b_y[o];
 }
 
+// Compaction of a wave: decided columns are swapped towards the tail so that the columns still
+// iterating fill the first tiles and later chunks launch fewer tiles.  grid (row chunks, pairs).
+__global__ __launch_bounds__(256) void kb_swap_cols(Dev d, int npairs) {
+  const int p = blockIdx.y;
+  if (p >= npairs) return;
+  const int a = d.c_pairs[2 * p], b = d.c_pairs[2 * p + 1];
+  const size_t Bs = (size_t)d.Bs;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+#define SWAPROW(arr, rows)                                  \
+  if (r < (rows)) {                                         \
+    const double t_ = arr[r * Bs + a];                      \
+    arr[r * Bs + a] = arr[r * Bs + b];                      \
+    arr[r * Bs + b] = t_;                                   \
+  }
+  SWAPROW(d.b_l, d.M) SWAPROW(d.b_u, d.M) SWAPROW(d.b_z, d.M) SWAPROW(d.b_y, d.M) SWAPROW(d.b_dy, d.M)
+  SWAPROW(d.b_wh, d.M + d.n)  // wh | rx
+  SWAPROW(d.b_x, d.n) SWAPROW(d.b_dx, d.n)
+#undef SWAPROW
+  if (r == 0) {
+#define SWAP1(T, arr) { const T t_ = arr[a]; arr[a] = arr[b]; arr[b] = t_; }
+    SWAP1(int, d.c_done) SWAP1(int, d.c_status) SWAP1(int, d.c_iter) SWAP1(int, d.c_node)
+    SWAP1(double, d.c_pri) SWAP1(double, d.c_dua) SWAP1(double, d.c_obj)
+#undef SWAP1
+  }
+}
+
 // unscale (or build the certificate) per column, then the integer clamp of node.py:131-136
 __global__ __launch_bounds__(1024) void kb_finish(Dev d, int B) {
   __shared__ double lds[16 * 64];
@@ -1826,7 +1855,8 @@ __global__ __launch_bounds__(1024) void kb_finish(Dev d, int B) {
     const double *rl = d.b_raw, *ru = rl + (size_t)B * M;
     for (int k = rg; k < d.n_int; k += 16) {
       const size_t o = (size_t)d.i_idx[k] * Bs + b;
-      const double lo = rl[(size_t)b * M + d.m_orig + k], hi = ru[(size_t)b * M + d.m_orig + k];
+      const size_t nb_ = (size_t)d.c_node[b];  // the node this column holds after compaction swaps
+      const double lo = rl[nb_ * M + d.m_orig + k], hi = ru[nb_ * M + d.m_orig + k];
       d.b_xfin[o] = fmin(fmax(d.b_xfin[o], lo), hi);
     }
   }
@@ -1997,6 +2027,8 @@ struct miosqp_qp_engine {
   double *hb_dbl = nullptr;    // pri | dua | obj | lower
   hipGraphExec_t xb_full[16] = {}, xb_tail[16] = {};
   hipGraph_t gb_full[16] = {}, gb_tail[16] = {};
+  bool compact = true;   // compaction of converged columns in solve_batch (MIOSQP_COMPACT=0 disables)
+  int64_t compactions = 0;
   double bloop_ms = 0.0;
   int64_t bloop_iters = 0, bloop_node_iters = 0;
 };
@@ -2265,7 +2297,7 @@ int alloc_batch(miosqp_qp_engine *e, int cap) {
   ALB(b_l, M * Bs); ALB(b_u, M * Bs); ALB(b_x, n * Bs); ALB(b_z, M * Bs); ALB(b_y, M * Bs); ALB(b_wh, (M + n) * Bs);
   ALB(b_cv, n * Bs); ALB(b_ut, n * Bs); ALB(b_xt, n * Bs); ALB(b_dx, n * Bs); ALB(b_dy, M * Bs);
   ALB(b_sm, 8 * M * Bs); ALB(b_sn, 4 * n * Bs); ALB(b_xfin, n * Bs); ALB(b_yfin, M * Bs); ALB(b_xi, n * Bs); ALB(b_xis, n * Bs);
-  ALB(c_intinf, Bs); ALB(c_nextvar, Bs); ALB(c_hviol, Bs); ALB(c_hobj, Bs);
+  ALB(c_intinf, Bs); ALB(c_nextvar, Bs); ALB(c_hviol, Bs); ALB(c_hobj, Bs); ALB(c_node, Bs); ALB(c_pairs, 2 * Bs);
   ALB(b_part, (Bs / 64) * 32 * 17 * 64);
   ALB(b_raw, Bs * (3 * M + n)); ALB(b_out, Bs * (n + M));
   ALB(c_done, Bs); ALB(c_status, Bs); ALB(c_iter, Bs); ALB(c_pri, Bs); ALB(c_dua, Bs); ALB(c_obj, Bs);
@@ -2274,7 +2306,7 @@ int alloc_batch(miosqp_qp_engine *e, int cap) {
   d.b_rx = d.b_wh + M * Bs;
   HIPCHK(hipHostMalloc((void **)&e->hb_in, sizeof(double) * Bs * (3 * M + n), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->hb_out, sizeof(double) * Bs * (n + M), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void **)&e->hb_int, sizeof(int) * 4 * Bs, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&e->hb_int, sizeof(int) * 6 * Bs, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void **)&e->hb_dbl, sizeof(double) * 6 * Bs, hipHostMallocDefault));
   e->Bcap = (int)Bs;
   return 0;
@@ -2308,9 +2340,10 @@ int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, co
   const int nfull = e->st.max_iter / e->chunk;
   bool done = false;
   int decided = 0;
+  int cur = ntiles;  // tiles still launched; shrinks as the wave is compacted
   for (int k = 0; k < nfull && !done; k++) {
     HIPCHK(hipEventRecord(e->evc0, e->stream));
-    HIPCHK(hipGraphLaunch(e->xb_full[ntiles - 1], e->stream));
+    HIPCHK(hipGraphLaunch(e->xb_full[cur - 1], e->stream));
     HIPCHK(hipEventRecord(e->evc1, e->stream));
     HIPCHK(hipMemcpyAsync(e->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -2321,8 +2354,41 @@ int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, co
     e->bloop_node_iters += (int64_t)e->chunk * (B - decided);  // columns still iterating in this chunk
     decided = e->h_ctrl->ndone;
     done = e->h_ctrl->done != 0;
+    const int active = B - decided, want = (active + 63) / 64;
+    if (!done && e->compact && want < cur) {
+      // move the still-iterating columns into the first `want` tiles
+      const int cols = cur * 64;
+      int *flags = e->hb_int;  // scratch: the info arrays are only filled at the end
+      HIPCHK(hipMemcpyAsync(flags, d.c_done, sizeof(int) * cols, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      int *pairs = e->hb_int + cols;
+      int np = 0, lo = 0, hi = cols - 1;
+      for (;;) {
+        while (lo < active && !flags[lo]) lo++;      // a decided column inside the front region
+        while (hi >= active && flags[hi]) hi--;      // a live column behind it
+        if (lo >= active || hi < active) break;
+        pairs[2 * np] = lo;
+        pairs[2 * np + 1] = hi;
+        np++;
+        flags[lo] = 0;
+        flags[hi] = 1;
+      }
+      if (np > 0) {
+        HIPCHK(hipMemcpyAsync(d.c_pairs, pairs, sizeof(int) * 2 * np, hipMemcpyHostToDevice, e->stream));
+        const int rows = (int)(M + n);
+        hipLaunchKernelGGL(kb_swap_cols, dim3((rows + 255) / 256, np), dim3(256), 0, e->stream, d, np);
+      }
+      cur = want;
+      if (!e->xb_full[cur - 1]) {
+        int rc = capture_chunk_b(e, e->chunk, cur, &e->gb_full[cur - 1], &e->xb_full[cur - 1]);
+        if (!rc && e->tail_iters > 0)
+          rc = capture_chunk_b(e, e->tail_iters, cur, &e->gb_tail[cur - 1], &e->xb_tail[cur - 1]);
+        if (rc) return rc;
+      }
+      e->compactions++;
+    }
   }
-  if (!done && e->tail_iters > 0) HIPCHK(hipGraphLaunch(e->xb_tail[ntiles - 1], e->stream));
+  if (!done && e->tail_iters > 0) HIPCHK(hipGraphLaunch(e->xb_tail[cur - 1], e->stream));
   hipLaunchKernelGGL(kb_finish, dim3(ntiles), dim3(1024), 0, e->stream, d, B);
   if (d.digest) hipLaunchKernelGGL(kb_heur_rows, dim3((d.M + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(kb_obj_rows, dim3((d.n + 3) / 4, ntiles), dim3(256), 0, e->stream, d);
@@ -2339,24 +2405,29 @@ int solve_slice(miosqp_qp_engine *e, int B, const double *l, const double *u, co
   HIPCHK(hipMemcpyAsync(e->hb_dbl + 5 * B, d.c_hobj, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->hb_int + 2 * B, d.c_intinf, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipMemcpyAsync(e->hb_int + 3 * B, d.c_nextvar, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->hb_int + 4 * B, d.c_node, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  memcpy(x_out, e->hb_out, sizeof(double) * B * n);
-  memcpy(y_out, e->hb_out + B * n, sizeof(double) * B * M);
+  const int *node_of = e->hb_int + 4 * B;  // column position -> node
+  for (int c = 0; c < B; c++) {
+    memcpy(x_out + (size_t)node_of[c] * n, e->hb_out + (size_t)c * n, sizeof(double) * n);
+    memcpy(y_out + (size_t)node_of[c] * M, e->hb_out + B * n + (size_t)c * M, sizeof(double) * M);
+  }
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
   const double wall_s = wall() - t0;
-  for (int b = 0; b < B; b++) {
-    info[b].status_val = e->hb_int[b];
-    info[b].iter = e->hb_int[B + b];
-    info[b].pri_res = e->hb_dbl[b];
-    info[b].dua_res = e->hb_dbl[B + b];
-    info[b].obj_val = e->hb_dbl[2 * B + b];
-    info[b].lower = e->hb_dbl[3 * B + b];
-    info[b].int_inf = d.digest ? e->hb_int[2 * B + b] : -1;
-    info[b].nextvar = d.digest ? e->hb_int[3 * B + b] : -1;
-    info[b].heur_viol = e->hb_dbl[4 * B + b];
-    info[b].heur_obj = e->hb_dbl[5 * B + b];
+  for (int c = 0; c < B; c++) {
+    const int b = node_of[c];
+    info[b].status_val = e->hb_int[c];
+    info[b].iter = e->hb_int[B + c];
+    info[b].pri_res = e->hb_dbl[c];
+    info[b].dua_res = e->hb_dbl[B + c];
+    info[b].obj_val = e->hb_dbl[2 * B + c];
+    info[b].lower = e->hb_dbl[3 * B + c];
+    info[b].int_inf = d.digest ? e->hb_int[2 * B + c] : -1;
+    info[b].nextvar = d.digest ? e->hb_int[3 * B + c] : -1;
+    info[b].heur_viol = e->hb_dbl[4 * B + c];
+    info[b].heur_obj = e->hb_dbl[5 * B + c];
     info[b].run_time = wall_s / B;  // the wave's wall time, shared equally
     info[b].device_time = 1e-3 * ms / B;
   }
@@ -2600,6 +2671,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         }
       }
       if (const char *ev = getenv("MIOSQP_BD_CFG")) e->bd_cfg = atoi(ev);
+      if (const char *ev = getenv("MIOSQP_COMPACT")) e->compact = atoi(ev) != 0;
       if (const char *ev = getenv("MIOSQP_BM_ABLATE")) d.bm_ablate = atoi(ev);
       if (const char *ev = getenv("MIOSQP_FOLD_TPR")) {  // tuning hook: "fwd,x,c"
         int a = 0, b = 0, c = 0;
@@ -2861,6 +2933,12 @@ int miosqp_qp_debug_clock(miosqp_qp_engine *e, double *cycles, double *ticks) {
   *cycles = c.nrm_dy;
   *ticks = c.nrm_dx;
   return 0;
+}
+
+// debug counters: 0 = wave compactions performed by solve_batch so far
+int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which) {
+  if (!e) return -1;
+  return which == 0 ? e->compactions : -1;
 }
 
 int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters, int64_t *node_iters,

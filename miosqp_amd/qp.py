@@ -221,6 +221,9 @@ class OSQP(object):
                "get_batch_stats")
         return ms.value, bi.value, ni.value
 
+    def compactions(self):
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 0))
+
     def time_kernel(self, which, reps=200):
         us, by = C.c_double(), C.c_double()
         _check(self._lib.miosqp_qp_time_kernel(self._h, which, reps, C.byref(us), C.byref(by)),

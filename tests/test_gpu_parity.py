@@ -263,10 +263,11 @@ def _wave_of_nodes(oracle_mod, pr, count):
     return nodes[:count]
 
 
-@pytest.mark.parametrize("n,m,p,seed,count,fold", [(20, 40, 10, 1, 7, -1), (50, 100, 25, 2, 70, 0),
-                                                    (50, 100, 25, 2, 70, 1), (130, 260, 65, 3, 130, -1),
-                                                    (37, 3, 20, 4, 9, 1), (33, 2, 16, 6, 9, 0)])
-def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold):
+@pytest.mark.parametrize("n,m,p,seed,count,fold,cap", [(20, 40, 10, 1, 7, -1, 64), (50, 100, 25, 2, 70, 0, 64),
+                                                        (50, 100, 25, 2, 70, 1, 64), (130, 260, 65, 3, 130, -1, 64),
+                                                        (37, 3, 20, 4, 9, 1, 64), (33, 2, 16, 6, 9, 0, 64),
+                                                        (130, 260, 65, 3, 200, -1, 256), (50, 100, 25, 2, 150, 0, 192)])
+def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold, cap):
     """solve_batch on a wave of real B&B leaves == solve_node on each == the oracle."""
     from miosqp_amd import qp
     pr = problems.random_miqp(n, m, p, seed=seed)
@@ -274,7 +275,8 @@ def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold):
     assert len(leaves) >= 2
     A, l, u = problems.extended(pr)
     g, o = qp.OSQP(), oracle_mod.OSQP()
-    g.setup(pr["P"], pr["q"], A, l, u, max_batch=64, fold=fold, **problems.QP_SETTINGS)  # 64 < count: slices
+    # cap 64 < count: the wave is cut into slices; cap >= 128: several tiles, compacted as columns finish
+    g.setup(pr["P"], pr["q"], A, l, u, max_batch=cap, fold=fold, **problems.QP_SETTINGS)
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
     g.set_integer_rows(pr["i_idx"], m)
     g.set_root(l, u, 1e-3, 1e-3)  # node digest on: integrality, branching variable, rounding heuristic
@@ -315,6 +317,8 @@ def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold):
             assert abs(db.heur_obj - ho) <= 1e-8 * max(1.0, abs(ho)) and abs(d1.heur_obj - ho) <= 1e-8 * max(1.0, abs(ho))
         else:
             assert np.isnan(rb.lower[k]) and rb.digest[k] is None
+    if cap >= 128 and len(leaves) > 128:
+        assert g.compactions() >= 1  # columns finish at different tests: the wave was compacted
     # a second identical call is bit-identical
     rb2 = g.solve_batch(L, U, X, Y)
     np.testing.assert_array_equal(rb.x, rb2.x)
