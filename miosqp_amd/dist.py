@@ -152,8 +152,19 @@ class ShardedSearch(object):
         exploration rule would visit them, then bound/branch each in that order."""
         w = self.work
         wave = []
-        while w.leaves and len(wave) < width:
-            wave.append(w.choose_leaf(rule))
+        if w.leaves:
+            # the `width` leaves that repeated choose_leaf() calls would pop, in that order: argmax
+            # with first-index ties == stable sort by descending key (workspace.py:128-155)
+            if rule == 0 or (rule == 1 and np.isinf(w.upper_glob)):
+                keys = np.array([lf.depth for lf in w.leaves], dtype=float)
+            elif rule == 1:
+                keys = np.array([lf.lower for lf in w.leaves], dtype=float)
+            else:
+                raise ValueError('Tree exploring strategy not recognized')
+            order = np.argsort(-keys, kind='stable')[:width]
+            wave = [w.leaves[i] for i in order]
+            taken = set(int(i) for i in order)
+            w.leaves = [lf for i, lf in enumerate(w.leaves) if i not in taken]
         if wave:
             w.solve_wave(wave)
             for leaf in wave:
