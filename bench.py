@@ -124,12 +124,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the relaxation engine has no CPU fallback")
+    # MIOSQP_BENCH_ONE_DEVICE=1: every rank uses GPU 0 and the collectives run over gloo (CPU tensors);
+    # only for exercising the multi-rank code path on a one-GPU box, never for reported numbers
+    one_dev = os.environ.get("MIOSQP_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as td
-        td.init_process_group(backend="nccl", device_id=dev)
-        comm = dist.TorchComm(dev)
+        if one_dev:
+            td.init_process_group(backend="gloo")
+            comm = dist.TorchComm(torch.device("cpu"))
+        else:
+            td.init_process_group(backend="nccl", device_id=dev)
+            comm = dist.TorchComm(dev)
     else:
         comm = dist.LocalComm()
     if args.gpus != world and rank == 0:
@@ -187,7 +196,7 @@ def main():
     dt_max = dt
     if world > 1:
         import torch.distributed as td
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=comm.device)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt_max = float(tmax.item())
     iters, nodes = float(tot[0]), float(tot[1])
@@ -209,7 +218,7 @@ def main():
         bms, bit, bnode = eng.batch_stats()
         totb = comm.sum([srch.iters - i1, srch.nodes - n1])
         if world > 1:
-            tb = torch.tensor([dtb], dtype=torch.float64, device=dev)
+            tb = torch.tensor([dtb], dtype=torch.float64, device=comm.device)
             td.all_reduce(tb, op=td.ReduceOp.MAX)
             dtb = float(tb.item())
         batched = dict(max_wave=args.batch_width, waves=args.batch_waves, nodes=float(totb[1]),
