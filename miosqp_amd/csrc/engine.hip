@@ -1975,15 +1975,6 @@ inline int pick_tpr(double avg_row) {
     }                                                                                             \
   } while (0)
 
-template <typename T>
-int upload(const std::vector<T> &h, T **dptr) {
-  size_t bytes = (h.size() + 64) * sizeof(T);  // zeroed slack: tile loads may overshoot the last row
-  HIPCHK(hipMalloc((void **)dptr, bytes));
-  HIPCHK(hipMemset(*dptr, 0, bytes));
-  if (h.size()) HIPCHK(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  return 0;
-}
-
 }  // namespace
 
 struct miosqp_qp_engine {
