@@ -65,7 +65,10 @@ typedef struct miosqp_qp_settings {
                                 product-form factor and all iterates fit in 160 KB of LDS */
   int32_t setup_on_device;   /* -1 auto (n >= 1024), 0 host, 1 device: dense LDL^T of the reduced Hessian and
                                 the inverse of its triangular factor computed on the GPU at setup */
-  int32_t reserved[3];
+  int32_t coop;              /* -1 auto, 0 off, 1 on: cooperative register-resident solver -- the explicit KKT
+                                inverse (n+M)^2 spread over the register files of up to one workgroup per
+                                CU, ONE exchange per iteration (needs the product form and n+M <= 2048) */
+  int32_t reserved[2];
 } miosqp_qp_settings;
 
 /* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus

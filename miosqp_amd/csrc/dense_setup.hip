@@ -255,3 +255,65 @@ done:
   hipFree(dflag);
   return rc;
 }
+
+// ------------------------------------------------------------------------------------------
+// Explicit KKT inverse for the register-resident cooperative solver (engine.hip, k_coop):
+//   W = F^T D22^-1 F ,   F = [ -G | L22^-1 ]  (n x N, N = M + n; the rows of the product-form
+//   factor with their unit diagonal restored),  so that  W [wh ; rx] = [ rho A x~ + .. ; x~ ].
+// One 64 x 64 tile of W per workgroup, 4 x 4 per thread, 16 factor rows per step through LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ks_kkt_inverse(const double *__restrict__ F, int ldf, const double *__restrict__ dinv,
+                                                      int n, int M, double *__restrict__ W, int ldw) {
+  __shared__ double As[16][64 + 1], Bs[16][64 + 1];
+  const int N = n + M;
+  const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4] = {};
+  // column c >= M of F is zero above row c - M
+  const int lo = a0 > b0 ? a0 : b0;
+  int i0 = lo > M ? ((lo - M) & ~15) : 0;
+  for (; i0 < n; i0 += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int k = e >> 6, c = e & 63, i = i0 + k;
+      double va = 0.0, vb = 0.0;
+      if (i < n) {
+        const int ca = a0 + c, cb = b0 + c;
+        const double di = dinv[i];
+        if (ca < N) va = (ca == M + i ? 1.0 : (ca > M + i ? 0.0 : F[(size_t)i * ldf + ca])) * di;
+        if (cb < N) vb = cb == M + i ? 1.0 : (cb > M + i ? 0.0 : F[(size_t)i * ldf + cb]);
+      }
+      As[k][c] = va;
+      Bs[k][c] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      double a[4], b[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        a[p] = As[k][ty + 16 * p];
+        b[p] = Bs[k][tx + 16 * p];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[p][q] = fma(a[p], b[q], acc[p][q]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int a = a0 + ty + 16 * p, b = b0 + tx + 16 * q;
+      if (a < N && b < N) W[(size_t)a * ldw + b] = acc[p][q];
+    }
+}
+
+// F, dinv, W are device pointers; runs on `stream`
+int miosqp_device_kkt_inverse(const double *F, int ldf, const double *dinv, int n, int M, double *W, int ldw,
+                              hipStream_t stream) {
+  const int N = n + M, nt = (N + 63) / 64;
+  hipLaunchKernelGGL(ks_kkt_inverse, dim3(nt, nt), dim3(256), 0, stream, F, ldf, dinv, n, M, W, ldw);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

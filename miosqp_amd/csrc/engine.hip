@@ -35,6 +35,9 @@
 
 // dense_setup.hip: dense LDL^T + triangular inverse on the device (miosqp::DenseLdlInv)
 int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double *Linv, double *LinvT, void *ctx);
+// dense_setup.hip: explicit KKT inverse W = F^T D22^-1 F from the product-form rows (device pointers)
+int miosqp_device_kkt_inverse(const double *F, int ldf, const double *dinv, int n, int M, double *W, int ldw,
+                              hipStream_t stream);
 
 namespace {
 
@@ -102,6 +105,17 @@ struct Dev {
   int digest;
   int bm_ablate;  // debug: 1 = no operand loads, 2 = no matrix-core instructions
   unsigned long long *prof;  // debug timeline (per-block start/end, 100 MHz wall clock) or nullptr
+  // ---- cooperative register-resident solver (k_coop): explicit KKT inverse, exchange buffers ----
+  const double *W;               // N x ldw, N = M + n, ordering [constraints ; variables]
+  int ldw;
+  unsigned *coop_tag;            // tag of the last exchange round that completed
+  unsigned long long *coop_buf;  // 2 parities x N x {lo32|tag, hi32|tag}
+  unsigned long long *coop_chk;  // 2 x coop_half: the test's operands [y ; x] and [proj(dy) ; dx]
+  unsigned long long *coop_q;    // T x COOP_QS: per-workgroup norms / sums of the test
+  const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
+  int coop_dbg;                  // debug ablation: 1 = no gather
+  int coop_stride;               // 8-byte words between the blocks of consecutive workgroups (>= 2 RW)
+  size_t coop_half;              // words per parity
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
   double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_rx, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
@@ -617,6 +631,381 @@ __global__ __launch_bounds__(256) void k_check_decide(Dev d, int iters_in_chunk)
 }
 
 // ------------------------------------------------------------------------------------------
+// cooperative register-resident solver: the same iteration as ONE exchange per step.
+//   [nu + rho wh ; x~] = W [wh ; rx],  W = K^-1 restricted as in dense_setup.hip (ks_kkt_inverse).
+// Workgroup b keeps rows [b RW, (b+1) RW) of W in registers for the whole launch (thread t holds
+// columns t + k*COOP_B, COOP_B threads per workgroup), owns the iterates of those rows, and after every step publishes its RW new
+// entries of [wh ; rx]; every workgroup then gathers the whole vector.  The exchange needs no
+// barrier and no flag: an entry travels as two 8-byte words {low half | tag}, {high half | tag}
+// (8-byte stores are single-copy atomic), written at agent scope into the buffer of the round's
+// parity, and a reader polls its own CPT entries until both tags match.  A workgroup can only
+// reach round k+1 after it has seen every entry of round k, so two buffers suffice.
+// The termination test runs inside the same launch (every `check_every` iterations): the owners
+// also publish [y ; x] and [proj(dy) ; dx], every workgroup applies ITS rows of
+//   Kc = [ 0  Abar ; Abar^T  Pbar ]   (read from HBM, only at a test)
+// to both, reduces the 17 norms / sums of sec. 3.4 over its rows, publishes them, gathers those of
+// all workgroups and takes the decision itself -- identical arithmetic in identical order
+// everywhere, so all workgroups agree without a further exchange.
+// All workgroups must be co-resident: the grid never exceeds the CU count and one workgroup fits
+// per CU next to anything else this engine launches.  Polling is bounded; on expiry ctrl->pad is
+// set and the host reports MIOSQP_EHIP.
+// ------------------------------------------------------------------------------------------
+#define COOP_SPIN_LIMIT (1u << 19)
+
+typedef unsigned ll_u4 __attribute__((ext_vector_type(4)));
+// one 16-byte agent-scope store / load per entry ({lo, tag, hi, tag}); the tags in BOTH 8-byte halves
+// keep the hand-off correct even if the 16 bytes were ever observed torn
+__device__ __forceinline__ void ll_publish(unsigned long long *slot, double v, unsigned tag) {
+  ll_u4 w;
+  w.x = (unsigned)__double2loint(v); w.y = tag; w.z = (unsigned)__double2hiint(v); w.w = tag;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(w) : "memory");
+}
+__device__ __forceinline__ ll_u4 ll_peek(const unsigned long long *slot) {
+  ll_u4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(slot) : "memory");
+  return w;
+}
+
+// transposed butterfly: RW values per lane in, the sum over the wave of ONE row per lane out
+// (row coop_row<RW>(lane)); halves the live values at every exchange instead of reducing each
+// row separately.  Partners: xor 1, xor 2 (quad_perm), 7 - i (row_half_mirror), 15 - i (row_mirror);
+// the keep/send choice of a stage must differ between partners of that stage and agree between
+// partners of every later stage, hence the mixed bits.
+template <int RW>
+__device__ __forceinline__ int coop_row(int lane) {
+  const int cA = (lane ^ (lane >> 2)) & 1, cB = ((lane >> 1) ^ (lane >> 2)) & 1, cC = ((lane >> 2) ^ (lane >> 3)) & 1,
+            cD = (lane >> 3) & 1;
+  return RW == 16 ? 8 * cA + 4 * cB + 2 * cC + cD : 4 * cA + 2 * cB + cC;
+}
+template <int RW>
+__device__ __forceinline__ double wave_tsum(double (&v)[RW], int lane) {
+  static_assert(RW == 8 || RW == 16, "rows per workgroup");
+  const bool cA = (lane ^ (lane >> 2)) & 1, cB = ((lane >> 1) ^ (lane >> 2)) & 1, cC = ((lane >> 2) ^ (lane >> 3)) & 1,
+             cD = (lane >> 3) & 1;
+#define HALVE(H, C, CTRL)                                        \
+  _Pragma("unroll") for (int k = 0; k < (H) / 2; k++) {          \
+    const double keep = (C) ? v[k + (H) / 2] : v[k];             \
+    const double send = (C) ? v[k] : v[k + (H) / 2];             \
+    v[k] = keep + dpp_get<CTRL>(send);                           \
+  }
+  if constexpr (RW == 16) {
+    HALVE(16, cA, 0xB1) HALVE(8, cB, 0x4E) HALVE(4, cC, 0x141) HALVE(2, cD, 0x140)
+  } else {
+    (void)cD;
+    HALVE(8, cA, 0xB1) HALVE(4, cB, 0x4E) HALVE(2, cC, 0x141)
+    v[0] += dpp_get<0x140>(v[0]);
+  }
+#undef HALVE
+  v[0] += __shfl_xor(v[0], 16, 64);
+  v[0] += __shfl_xor(v[0], 32, 64);
+  return v[0];
+}
+
+constexpr int COOP_QS = 48;  // 8-byte words per workgroup in the norm exchange (NQ entries of 2 words, padded)
+
+template <int COOP_B, int RW, int CPT>
+__global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_every, int final_check) {
+  if (d.ctrl->done) return;
+  constexpr int NW = COOP_B / 64, NG = COOP_B / 32;
+  static_assert(NQ <= 32 && NG * 16 >= 256, "norm gather layout");
+  __shared__ double part[2][NW][RW];
+  __shared__ double cpart[4][NW][RW];
+  __shared__ double qrow[RW][NQ];
+  __shared__ double qred[NG][NQ];
+  __shared__ double qres[NQ];
+  __shared__ int s_fail, s_status;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int M = d.M, N = d.n + d.M, T = gridDim.x;
+  const int r0 = blockIdx.x * RW;
+  const unsigned base = *d.coop_tag;
+  double Kr[RW][CPT], v[CPT];
+  int slot[CPT];  // word offset of this thread's columns inside an exchange buffer
+#pragma unroll
+  for (int k = 0; k < CPT; k++) {
+    const int c = t + k * COOP_B;
+    v[k] = c < N ? d.wh[c] : 0.0;
+    slot[k] = (c / RW) * d.coop_stride + 2 * (c % RW);
+#pragma unroll
+    for (int rw = 0; rw < RW; rw++) Kr[rw][k] = (c < N && r0 + rw < N) ? d.W[(size_t)(r0 + rw) * d.ldw + c] : 0.0;
+  }
+  // iterates of the row this thread owns (threads 0..RW-1)
+  const int r = r0 + t;
+  const bool own = t < RW && r < N, con = r < M;
+  double sa = 0.0, sb = 0.0, lo = 0.0, up = 0.0, sw = 0.0, delta = 0.0;  // (z, y, l, u, wh, dy) or (x, q, -, -, -, dx)
+  if (own) {
+    if (con) { sa = d.z[r]; sb = d.y[r]; lo = d.l[r]; up = d.u[r]; sw = d.wh[r]; }
+    else { sa = d.x[r - M]; sb = d.q[r - M]; }
+  }
+  if (t == 0) { s_fail = 0; s_status = 0; }
+  __syncthreads();
+  const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha, sigma = d.sigma;
+  const size_t my_slot = (size_t)blockIdx.x * d.coop_stride + 2 * t;
+
+  // all CPT entries of this thread's columns from one exchange buffer; waits for the LAST column
+  // alone first (fewer requests in flight while nothing has arrived yet)
+  auto gather = [&](const unsigned long long *buf, unsigned tag, double (&out)[CPT]) {
+    bool have[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; k++) have[k] = t + k * COOP_B >= N;
+    unsigned spins = 0;
+    if (!have[CPT - 1]) {
+      for (;;) {
+        const ll_u4 w = ll_peek(buf + slot[CPT - 1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (w.y == tag && w.w == tag) {
+          out[CPT - 1] = __hiloint2double((int)w.z, (int)w.x);
+          have[CPT - 1] = true;
+          break;
+        }
+        if (++spins > COOP_SPIN_LIMIT) break;
+      }
+    }
+    for (;;) {
+      ll_u4 w[CPT];
+#pragma unroll
+      for (int k = 0; k < CPT; k++)
+        if (!have[k]) w[k] = ll_peek(buf + slot[k]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bool all = true;
+#pragma unroll
+      for (int k = 0; k < CPT; k++)
+        if (!have[k]) {
+          if (w[k].y == tag && w[k].w == tag) {
+            out[k] = __hiloint2double((int)w[k].z, (int)w[k].x);
+            have[k] = true;
+          } else {
+            all = false;
+          }
+        }
+      if (all) break;
+      if (++spins > COOP_SPIN_LIMIT) {
+        s_fail = 1;
+        d.ctrl->pad = 1;
+        break;
+      }
+    }
+  };
+
+  long long ph0 = 0, ph1 = 0, ph2 = 0;  // debug phase clocks (thread 0, d.prof set)
+  int it = 0, status = 0;
+  for (it = 1; it <= max_iter; it++) {
+    const unsigned tag = base + (unsigned)it;
+    const bool chk = (check_every > 0 && it % check_every == 0) || (final_check && it == max_iter);
+    const long long c0 = d.prof ? clock64() : 0;
+    double acc[RW];
+#pragma unroll
+    for (int rw = 0; rw < RW; rw++) {
+      double a = Kr[rw][0] * v[0];
+#pragma unroll
+      for (int k = 1; k < CPT; k++) a = fma(Kr[rw][k], v[k], a);
+      acc[rw] = a;
+    }
+    const double ws = wave_tsum<RW>(acc, lane);
+    if (lane < RW) part[it & 1][wave][coop_row<RW>(lane)] = ws;
+    __syncthreads();
+    if (s_fail) break;
+    const long long c1 = d.prof ? clock64() : 0;
+    unsigned long long *buf = d.coop_buf + (size_t)(tag & 1u) * d.coop_half;
+    double vproj = 0.0;
+    if (own) {
+      double s = part[it & 1][0][t];
+#pragma unroll
+      for (int w = 1; w < NW; w++) s += part[it & 1][w][t];
+      double pub;
+      if (con) {
+        const double nu = -rho * sw + s;
+        const double zt = sa + rinv * (nu - sb);
+        const double zr = alpha * zt + (1.0 - alpha) * sa;
+        const double zn = fmin(fmax(zr + rinv * sb, lo), up);
+        delta = rho * (zr - zn);
+        sa = zn;
+        sb += delta;
+        sw = zn - rinv * sb;
+        pub = sw;
+      } else {
+        const double xn = alpha * s + (1.0 - alpha) * sa;
+        delta = xn - sa;
+        sa = xn;
+        pub = sigma * xn - sb;
+      }
+      ll_publish(buf + my_slot, pub, tag);
+      if (chk) {  // the test's operands travel with the same round: [y ; x] and [proj(dy) ; dx]
+        if (con) {
+          const bool uinf = up > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
+          vproj = delta;
+          if (uinf && linf) vproj = 0.0;
+          else if (uinf) vproj = fmin(vproj, 0.0);
+          else if (linf) vproj = fmax(vproj, 0.0);
+        }
+        ll_publish(d.coop_chk + my_slot, con ? sb : sa, tag);
+        ll_publish(d.coop_chk + d.coop_half + my_slot, con ? vproj : delta, tag);
+      }
+    }
+    const long long c2 = d.prof ? clock64() : 0;
+    if (!(d.coop_dbg & 1)) gather(buf, tag, v);
+    if (d.prof) {
+      ph0 += c1 - c0; ph1 += c2 - c1; ph2 += clock64() - c2;
+    }
+    if (!chk) continue;
+
+    // ---- termination test ----
+    // two passes over this workgroup's rows of Kc, one per operand (the second pass finds the rows
+    // in L2); columns < M of a variable row are Abar^T, the others Pbar (Abar for a constraint row)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+      double vv[CPT];
+      gather(d.coop_chk + pass * d.coop_half, tag, vv);
+      double aA[RW], aP[RW];
+#pragma unroll
+      for (int rw = 0; rw < RW; rw++) aA[rw] = aP[rw] = 0.0;
+#pragma unroll
+      for (int k = 0; k < CPT; k++) {
+        const int c = t + k * COOP_B;
+        if (c >= N) continue;
+        const bool left = c < M;
+#pragma unroll
+        for (int rw = 0; rw < RW; rw++) {
+          const int rr = r0 + rw;
+          if (rr >= N || (left && rr < M)) continue;
+          const double a = d.Kc[(size_t)rr * d.ldw + c];
+          if (left) aA[rw] = fma(a, vv[k], aA[rw]);
+          else aP[rw] = fma(a, vv[k], aP[rw]);
+        }
+      }
+      const double w0 = wave_tsum<RW>(aA, lane), w1 = wave_tsum<RW>(aP, lane);
+      if (lane < RW) {
+        const int rr = coop_row<RW>(lane);
+        cpart[pass][wave][rr] = w0;       // A^T y | A^T proj(dy)
+        cpart[2 + pass][wave][rr] = w1;   // P x (A x) | P dx (A dx)
+      }
+    }
+    __syncthreads();
+    if (s_fail) break;
+    if (t < RW) {
+#pragma unroll
+      for (int k = 0; k < NQ; k++) qrow[t][k] = (k == 4 || k == 5) ? -1.7e308 : 0.0;
+      if (own) {
+        double sA1 = cpart[0][0][t], sA2 = cpart[1][0][t], sP1 = cpart[2][0][t], sP2 = cpart[3][0][t];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+          sA1 += cpart[0][w][t]; sA2 += cpart[1][w][t]; sP1 += cpart[2][w][t]; sP2 += cpart[3][w][t];
+        }
+        if (con) {
+          const double ei = d.Einv[r];
+          const bool uinf = up > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
+          const double adx = ei * sP2;
+          qrow[t][0] = fabs(ei * (sP1 - sa));
+          qrow[t][1] = fabs(ei * sP1);
+          qrow[t][2] = fabs(ei * sa);
+          qrow[t][3] = fabs(d.E[r] * vproj);
+          qrow[t][4] = uinf ? -1.7e308 : adx;
+          qrow[t][5] = -(linf ? 1.7e308 : adx);
+          qrow[t][13] = up * fmax(vproj, 0.0) + lo * fmin(vproj, 0.0);
+        } else {
+          const int i = r - M;
+          const double di = d.Dinv[i], px = sP1, aty = sA1;
+          qrow[t][6] = fabs(di * (px + sb + aty));
+          qrow[t][7] = fabs(di * px);
+          qrow[t][8] = fabs(di * aty);
+          qrow[t][9] = fabs(di * sb);
+          qrow[t][10] = fabs(di * sP2);
+          qrow[t][11] = fabs(di * sA2);
+          qrow[t][12] = fabs(d.D[i] * delta);
+          qrow[t][14] = sb * delta;
+          qrow[t][15] = sa * px;
+          qrow[t][16] = sb * sa;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < NQ) {
+      double rq = qrow[0][t];
+      for (int w = 1; w < RW; w++) rq = t < NQ_MAX ? fmax(rq, qrow[w][t]) : rq + qrow[w][t];
+      ll_publish(d.coop_q + (size_t)blockIdx.x * COOP_QS + 2 * t, rq, tag);
+    }
+    {
+      // quantity q = t % 32 over workgroups g, g + NG, g + 2 NG, ... (g = t / 32), fixed order
+      const int q = t & 31, g = t >> 5;
+      double rq = (q == 4 || q == 5) ? -1.7e308 : 0.0;
+      if (q < NQ) {
+        for (int wg = g; wg < T; wg += NG) {
+          const unsigned long long *p = d.coop_q + (size_t)wg * COOP_QS + 2 * q;
+          unsigned spins = 0;
+          for (;;) {
+            const ll_u4 w = ll_peek(p);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (w.y == tag && w.w == tag) {
+              const double val = __hiloint2double((int)w.z, (int)w.x);
+              rq = q < NQ_MAX ? fmax(rq, val) : rq + val;
+              break;
+            }
+            if (++spins > COOP_SPIN_LIMIT) {
+              s_fail = 1;
+              d.ctrl->pad = 1;
+              break;
+            }
+          }
+        }
+        qred[g][q] = rq;
+      }
+    }
+    __syncthreads();
+    if (s_fail) break;
+    if (t < NQ) {
+      double rq = qred[0][t];
+      for (int g = 1; g < NG; g++) rq = t < NQ_MAX ? fmax(rq, qred[g][t]) : rq + qred[g][t];
+      qres[t] = rq;
+    }
+    __syncthreads();
+    if (t == 0) {
+      Norms nm{qres[0], qres[1], qres[2], qres[3], qres[4], -qres[5], qres[6] * d.cinv, qres[7], qres[8], qres[9],
+               qres[10], qres[11], qres[12], qres[13], qres[14], qres[15], qres[16]};
+      double obj;
+      const int st = decide_status(d, nm, obj);
+      if (blockIdx.x == 0) {
+        Ctrl *c = d.ctrl;
+        c->iter = it;
+        c->pri_res = nm.pri;
+        c->dua_res = nm.dua;
+        c->obj_val = obj;
+        if (st) {
+          c->status = st;
+          c->done = 1;
+        }
+      }
+      s_status = st;
+    }
+    __syncthreads();
+    status = s_status;
+    if (status) break;
+  }
+  if (it > max_iter) it = max_iter;
+  if (d.prof && t == 0) {
+    d.prof[4 * blockIdx.x] = ph0; d.prof[4 * blockIdx.x + 1] = ph1; d.prof[4 * blockIdx.x + 2] = ph2;
+    d.prof[4 * blockIdx.x + 3] = it;
+  }
+  if (own) {
+    if (con) { d.z[r] = sa; d.y[r] = sb; d.dy[r] = delta; d.wh[r] = sw; }
+    else { d.x[r - M] = sa; d.dx[r - M] = delta; d.rx[r - M] = sigma * sa - sb; }
+  }
+  if (blockIdx.x == 0 && t == 0) {
+    *d.coop_tag = base + (unsigned)it;
+    if (!final_check) d.ctrl->iter = it;
+  }
+}
+
+// Kc = [ 0  Abar ; Abar^T  Pbar ] dense, N x ldw, from the dense copies of the scaled matrices
+__global__ void k_build_kc(Dev d, double *Kc) {
+  const int N = d.n + d.M, M = d.M;
+  const int rr = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  double a;
+  if (rr < M) a = c < M ? 0.0 : d.f_Ad[(size_t)rr * d.ldn + (c - M)];
+  else a = c < M ? d.f_Atd[(size_t)(rr - M) * d.ldm + c] : d.f_Pd[(size_t)(rr - M) * d.ldn + (c - M)];
+  Kc[(size_t)rr * d.ldw + c] = a;
+}
+
+// ------------------------------------------------------------------------------------------
 // LDS-resident solver for small problems (BASELINE configs 1 and 4): ONE workgroup keeps the
 // product-form factor -- the n x (M+n) matrix [ -G | strict_lower(Linv) ] -- and every iterate
 // in LDS and runs the WHOLE ADMM loop, termination tests included, in a single launch; the two
@@ -891,6 +1280,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_resident(Dev d, int max_iter, i
 __global__ void k_reset_ctrl(Dev d) {
   Ctrl *c = d.ctrl;
   c->done = 0;
+  c->pad = 0;  // cooperative solver: exchange timed out
   c->status = MIOSQP_QP_UNSOLVED;
   c->iter = 0;
   c->pri_res = c->dua_res = c->obj_val = 0.0;
@@ -2007,6 +2397,8 @@ struct miosqp_qp_engine {
   Ctrl *h_ctrl2 = nullptr;  // two pinned slots for the pipelined chunk loop
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   bool resident = false;  // whole solve in one LDS-resident workgroup (small problems)
+  bool coop = false;      // register-resident cooperative solver (k_coop), one exchange per iteration
+  int coop_rw = 8, coop_cpt = 4, coop_T = 0;
   int res_tg1 = 64, res_tg2 = 64;
   size_t res_lds = 0;
   miosqp::Folded fo;
@@ -2099,8 +2491,22 @@ int launch_resident(miosqp_qp_engine *e, int max_iter, int check_every, int fina
   return 0;
 }
 
+void launch_coop(miosqp_qp_engine *e, int max_iter, int check_every, int final_check) {
+  const Dev &d = e->d;
+#define CO(B, RW, CPT)                                                                                   \
+  hipLaunchKernelGGL((k_coop<B, RW, CPT>), dim3(e->coop_T), dim3(B), 0, e->stream, d, max_iter, check_every, \
+                     final_check)
+  if (e->coop_cpt == 2) CO(512, 8, 2);
+  else CO(512, 8, 4);
+#undef CO
+}
+
 void launch_iteration(miosqp_qp_engine *e) {
   const Dev &d = e->d;
+  if (e->coop) {
+    launch_coop(e, 1, 0, 0);
+    return;
+  }
   if (e->fold) {
     launch_fold_fwd(e);
     launch_fold_bwd(e);
@@ -2140,6 +2546,13 @@ int run_loop(miosqp_qp_engine *e) {
     HIPCHK(hipEventRecord(e->evc0, e->stream));
     int rc = launch_resident(e, e->st.max_iter, e->st.check_termination, 1);
     if (rc) return rc;
+    HIPCHK(hipEventRecord(e->evc1, e->stream));
+    e->res_pending = true;
+    return 0;
+  }
+  if (e->coop) {  // the cooperative solver runs the whole loop, tests included, in one launch
+    HIPCHK(hipEventRecord(e->evc0, e->stream));
+    launch_coop(e, e->st.max_iter, e->st.check_termination, 1);
     HIPCHK(hipEventRecord(e->evc1, e->stream));
     e->res_pending = true;
     return 0;
@@ -2184,6 +2597,10 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
   HIPCHK(hipMemcpyAsync(e->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->h_ctrl->pad) {
+    g_err = "cooperative solver: exchange timed out (workgroups not co-resident?)";
+    return MIOSQP_EHIP;
+  }
   memcpy(x_out, e->h_out, sizeof(double) * e->n);
   memcpy(y_out, e->h_out + e->n, sizeof(double) * e->M);
   float ms = 0;
@@ -2453,6 +2870,7 @@ int miosqp_qp_default_settings(miosqp_qp_settings *s) {
   s->fold = -1;
   s->resident = -1;
   s->setup_on_device = -1;
+  s->coop = -1;
   return 0;
 }
 
@@ -2661,6 +3079,54 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           }
         }
       }
+      {
+        // cooperative register-resident solver: the explicit KKT inverse spread over the register
+        // files of up to one workgroup per CU
+        const int N = n + M;
+        int wantc = s->coop;
+        if (const char *ev = getenv("MIOSQP_COOP")) wantc = atoi(ev);
+        int dev_now = 0;
+        HIPCHK(hipGetDevice(&dev_now));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, dev_now));
+        const int rw = 8;
+        if (const char *ev = getenv("MIOSQP_COOP_DBG")) d.coop_dbg = atoi(ev);
+        const int T = (N + rw - 1) / rw;
+        const bool can = !e->resident && N <= 2048 && T <= prop.multiProcessorCount;
+        if (wantc < 0) wantc = can && N >= 256 ? 1 : 0;
+        if (wantc && can) {
+          e->coop = true;
+          e->coop_rw = rw;
+          e->coop_cpt = N <= 1024 ? 2 : 4;
+          e->coop_T = T;
+          d.ldw = (N + 7) & ~7;
+          double *Wd = nullptr;
+          rc = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
+          if (!rc) rc = dalloc(e, &d.coop_tag, 64);
+          d.coop_stride = 2 * rw;
+          if (const char *ev = getenv("MIOSQP_COOP_STRIDE")) d.coop_stride = std::max(2 * rw, atoi(ev) / 8);
+          d.coop_half = (size_t)T * d.coop_stride;
+          int memkind = 0;
+          if (const char *ev = getenv("MIOSQP_COOP_MEM")) memkind = atoi(ev);
+          if (!rc && memkind) {
+            void *pb = nullptr;
+            const size_t bytes = (2 * d.coop_half + 64) * 8;
+            HIPCHK(hipExtMallocWithFlags(&pb, bytes, memkind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
+            HIPCHK(hipMemset(pb, 0, bytes));
+            e->allocs.push_back(pb);
+            d.coop_buf = (unsigned long long *)pb;
+          } else if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
+          if (!rc) rc = dalloc(e, &d.coop_chk, 2 * d.coop_half + 64);
+          if (!rc) rc = dalloc(e, &d.coop_q, (size_t)T * COOP_QS + 64);
+          double *Kc = nullptr;
+          if (!rc) rc = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
+          if (!rc) rc = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
+          if (rc) { miosqp_qp_cleanup(e); return rc; }
+          d.W = Wd;
+          d.Kc = Kc;
+          hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
+        }
+      }
       if (const char *ev = getenv("MIOSQP_BD_CFG")) e->bd_cfg = atoi(ev);
       if (const char *ev = getenv("MIOSQP_COMPACT")) e->compact = atoi(ev) != 0;
       if (const char *ev = getenv("MIOSQP_BM_ABLATE")) d.bm_ablate = atoi(ev);
@@ -2682,7 +3148,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->chunk = e->st.check_termination;
   e->tail_iters = e->st.max_iter % e->chunk;
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (!e->resident) {  // the LDS-resident solver needs no captured chunk
+  if (!e->resident && !e->coop) {  // the single-launch solvers need no captured chunk
     int rc = capture_chunk(e, e->chunk, &e->g_full, &e->x_full);
     if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
     if (rc) { miosqp_qp_cleanup(e); return rc; }
@@ -2841,6 +3307,8 @@ int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z
       int rc = launch_resident(e, k, 0, 0);
       if (rc) return rc;
     }
+  } else if (e->coop) {
+    if (k > 0) launch_coop(e, k, 0, 0);
   } else {
     for (int i = 0; i < k; i++) launch_iteration(e);
   }
@@ -2880,7 +3348,7 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[1] = e->fa.nnz_panel;
   out[2] = e->n;
   out[3] = (int64_t)b[4];
-  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0);
+  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0);
   return 0;
 }
 
@@ -2898,14 +3366,17 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 // debug: per-block (start, end) wall-clock stamps (100 MHz) of ONE launch of a product-form kernel
 int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
                              int32_t *nblocks) {
-  if (!e || !out || !e->fold || which < 0 || which > 1) return MIOSQP_EARG;
+  if (!e || !out || !e->fold || which < 0 || which > 2 || (which == 2 && !e->coop)) return MIOSQP_EARG;
   unsigned long long *buf = nullptr;
   HIPCHK(hipMalloc((void **)&buf, sizeof(unsigned long long) * 2 * 8192));
   HIPCHK(hipMemset(buf, 0, sizeof(unsigned long long) * 2 * 8192));
   for (int i = 0; i < 20; i++) launch_iteration(e);
   Dev saved = e->d;
   e->d.prof = buf;
-  if (which == 0) launch_fold_fwd(e); else launch_fold_bwd(e);
+  // which == 2: 1000 iterations of the cooperative solver; per workgroup {reduce, update+publish,
+  // gather} shader clocks of thread 0 and its poll rounds (4 words per workgroup)
+  if (which == 2) launch_coop(e, 1000, 0, 0);
+  else if (which == 0) launch_fold_fwd(e); else launch_fold_bwd(e);
   e->d = saved;
   HIPCHK(hipStreamSynchronize(e->stream));
   const int nb = max_blocks < 8192 ? max_blocks : 8192;

@@ -13,7 +13,7 @@ constant = oracle.constant
 
 class OSQP(oracle.OSQP):
     def setup(self, P=None, q=None, A=None, l=None, u=None, **kw):
-        kw = {k: v for k, v in kw.items() if k not in ("max_batch", "fold", "resident", "device", "setup_on_device")}
+        kw = {k: v for k, v in kw.items() if k not in ("max_batch", "fold", "resident", "device", "setup_on_device", "coop")}
         self._P, self._q, self._A = P.tocsc(), np.array(q, dtype=float), A.tocsc()
         self._root = None
         oracle.OSQP.setup(self, P, q, A, l, u, **kw)
