@@ -112,6 +112,7 @@ struct Dev {
   unsigned long long *coop_buf;  // 2 parities x N x {lo32|tag, hi32|tag}
   unsigned long long *coop_chk;  // 2 x coop_half: the test's operands [y ; x] and [proj(dy) ; dx]
   unsigned long long *coop_q;    // T x COOP_QS: per-workgroup norms / sums of the test
+  unsigned *coop_reg;            // start-up registration counter (zeroed before every launch)
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
   int coop_dbg;                  // debug ablation: 1 = no gather
   int coop_stride;               // 8-byte words between the blocks of consecutive workgroups (>= 2 RW)
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(256) void k_check_decide(Dev d, int iters_in_chunk)
 // cooperative register-resident solver: the same iteration as ONE exchange per step.
 //   [nu + rho wh ; x~] = W [wh ; rx],  W = K^-1 restricted as in dense_setup.hip (ks_kkt_inverse).
 // Workgroup b keeps rows [b RW, (b+1) RW) of W in registers for the whole launch (thread t holds
-// columns t + k*COOP_B, COOP_B threads per workgroup), owns the iterates of those rows, and after every step publishes its RW new
+// columns t + k*COOP_B, COOP_B = 256 threads per workgroup: one wave per SIMD, 512 registers each), owns the iterates of those rows, and after every step publishes its RW new
 // entries of [wh ; rx]; every workgroup then gathers the whole vector.  The exchange needs no
 // barrier and no flag: an entry travels as two 8-byte words {low half | tag}, {high half | tag}
 // (8-byte stores are single-copy atomic), written at agent scope into the buffer of the round's
@@ -707,9 +708,15 @@ template <int COOP_B, int RW, int CPT>
 __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_every, int final_check) {
   if (d.ctrl->done) return;
   constexpr int NW = COOP_B / 64, NG = COOP_B / 32;
-  static_assert(NQ <= 32 && NG * 16 >= 256, "norm gather layout");
+  static_assert(NQ <= 32, "norm gather layout");
+  // test scratch, two uses that never overlap in time: the operands lv[2][2048] (N <= 2048), then the
+  // gathered partial results qall[T * NQ] (at most 256 workgroups)
+  __shared__ __attribute__((aligned(16))) double tsc[256 * NQ];
+  static_assert(256 * NQ >= 4096, "operand staging");
+  double *const qall = tsc;
+  double(*const lv)[2048] = reinterpret_cast<double(*)[2048]>(tsc);
   __shared__ double part[2][NW][RW];
-  __shared__ double cpart[4][NW][RW];
+  __shared__ double cpart[4][1][RW];
   __shared__ double qrow[RW][NQ];
   __shared__ double qred[NG][NQ];
   __shared__ double qres[NQ];
@@ -736,7 +743,21 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
     if (con) { sa = d.z[r]; sb = d.y[r]; lo = d.l[r]; up = d.u[r]; sw = d.wh[r]; }
     else { sa = d.x[r - M]; sb = d.q[r - M]; }
   }
-  if (t == 0) { s_fail = 0; s_status = 0; }
+  // start-up: every workgroup registers and waits for all the others -- the proof that the whole
+  // grid is resident before anybody starts to depend on it
+  if (t == 0) {
+    s_fail = 0;
+    s_status = 0;
+    __hip_atomic_fetch_add(d.coop_reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(d.coop_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)T) {
+      if (++spins > COOP_SPIN_LIMIT) {
+        s_fail = 1;
+        d.ctrl->pad = 1;
+        break;
+      }
+    }
+  }
   __syncthreads();
   const double rho = d.rho, rinv = d.rho_inv, alpha = d.alpha, sigma = d.sigma;
   const size_t my_slot = (size_t)blockIdx.x * d.coop_stride + 2 * t;
@@ -748,7 +769,7 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
 #pragma unroll
     for (int k = 0; k < CPT; k++) have[k] = t + k * COOP_B >= N;
     unsigned spins = 0;
-    if (!have[CPT - 1]) {
+    if (!have[CPT - 1] && !(d.coop_dbg & 32)) {
       for (;;) {
         const ll_u4 w = ll_peek(buf + slot[CPT - 1]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -786,11 +807,15 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
     }
   };
 
-  long long ph0 = 0, ph1 = 0, ph2 = 0;  // debug phase clocks (thread 0, d.prof set)
-  int it = 0, status = 0;
+  long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph5 = 0, nchk = 0;  // debug phase clocks (thread 0, d.prof set)
+  int it = 0, status = 0, to_test = check_every > 0 ? check_every : -1;
   for (it = 1; it <= max_iter; it++) {
     const unsigned tag = base + (unsigned)it;
-    const bool chk = (check_every > 0 && it % check_every == 0) || (final_check && it == max_iter);
+    bool chk = final_check && it == max_iter;
+    if (--to_test == 0) {
+      chk = true;
+      to_test = check_every;
+    }
     const long long c0 = d.prof ? clock64() : 0;
     double acc[RW];
 #pragma unroll
@@ -849,34 +874,56 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
     if (!chk) continue;
 
     // ---- termination test ----
-    // two passes over this workgroup's rows of Kc, one per operand (the second pass finds the rows
-    // in L2); columns < M of a variable row are Abar^T, the others Pbar (Abar for a constraint row)
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
+    const long long k0 = d.prof ? clock64() : 0;
+    // both operands go to LDS; wave w then applies rows 2w, 2w+1 of this workgroup's block of Kc to
+    // them (rows are read once, 16 bytes per lane; a constraint row only has its Abar part).
+    // Columns < M of a variable row are Abar^T, the others Pbar.
+    {
       double vv[CPT];
-      gather(d.coop_chk + pass * d.coop_half, tag, vv);
-      double aA[RW], aP[RW];
+      gather(d.coop_chk, tag, vv);
 #pragma unroll
-      for (int rw = 0; rw < RW; rw++) aA[rw] = aP[rw] = 0.0;
+      for (int k = 0; k < CPT; k++)
+        if (t + k * COOP_B < N) lv[0][t + k * COOP_B] = vv[k];
+      gather(d.coop_chk + d.coop_half, tag, vv);
 #pragma unroll
-      for (int k = 0; k < CPT; k++) {
-        const int c = t + k * COOP_B;
-        if (c >= N) continue;
-        const bool left = c < M;
+      for (int k = 0; k < CPT; k++)
+        if (t + k * COOP_B < N) lv[1][t + k * COOP_B] = vv[k];
+    }
+    __syncthreads();
+    if (s_fail) break;
+    {
+      static_assert(RW == 2 * NW, "two rows per wave");
+      double a8[8];  // per row: A^T y, A^T proj(dy), P x (A x), P dx (A dx)
 #pragma unroll
-        for (int rw = 0; rw < RW; rw++) {
-          const int rr = r0 + rw;
-          if (rr >= N || (left && rr < M)) continue;
-          const double a = d.Kc[(size_t)rr * d.ldw + c];
-          if (left) aA[rw] = fma(a, vv[k], aA[rw]);
-          else aP[rw] = fma(a, vv[k], aP[rw]);
+      for (int k = 0; k < 8; k++) a8[k] = 0.0;
+      const int Ne = N & ~1;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int rr = r0 + 2 * wave + h;
+        if (rr >= N) continue;
+        const double *row = d.Kc + (size_t)rr * d.ldw;
+        double sA1 = 0.0, sA2 = 0.0, sP1 = 0.0, sP2 = 0.0;
+#pragma unroll 4
+        for (int c = (rr < M ? (M & ~1) : 0) + 2 * lane; c < Ne; c += 128) {
+          const double2 a = *reinterpret_cast<const double2 *>(row + c);
+          const double2 p = *reinterpret_cast<const double2 *>(&lv[0][c]);
+          const double2 s2 = *reinterpret_cast<const double2 *>(&lv[1][c]);
+          if (c < M) { sA1 = fma(a.x, p.x, sA1); sA2 = fma(a.x, s2.x, sA2); }
+          else { sP1 = fma(a.x, p.x, sP1); sP2 = fma(a.x, s2.x, sP2); }
+          if (c + 1 < M) { sA1 = fma(a.y, p.y, sA1); sA2 = fma(a.y, s2.y, sA2); }
+          else { sP1 = fma(a.y, p.y, sP1); sP2 = fma(a.y, s2.y, sP2); }
         }
+        if ((N & 1) && lane == 0) {  // last column of an odd width (always a variable column)
+          const double a = row[N - 1];
+          sP1 = fma(a, lv[0][N - 1], sP1);
+          sP2 = fma(a, lv[1][N - 1], sP2);
+        }
+        a8[4 * h] = sA1; a8[4 * h + 1] = sA2; a8[4 * h + 2] = sP1; a8[4 * h + 3] = sP2;
       }
-      const double w0 = wave_tsum<RW>(aA, lane), w1 = wave_tsum<RW>(aP, lane);
-      if (lane < RW) {
-        const int rr = coop_row<RW>(lane);
-        cpart[pass][wave][rr] = w0;       // A^T y | A^T proj(dy)
-        cpart[2 + pass][wave][rr] = w1;   // P x (A x) | P dx (A dx)
+      const double ws8 = wave_tsum<8>(a8, lane);
+      if (lane < 8) {
+        const int e = coop_row<8>(lane);  // = 4 h + quantity
+        cpart[e & 3][0][2 * wave + (e >> 2)] = ws8;
       }
     }
     __syncthreads();
@@ -885,11 +932,7 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
 #pragma unroll
       for (int k = 0; k < NQ; k++) qrow[t][k] = (k == 4 || k == 5) ? -1.7e308 : 0.0;
       if (own) {
-        double sA1 = cpart[0][0][t], sA2 = cpart[1][0][t], sP1 = cpart[2][0][t], sP2 = cpart[3][0][t];
-#pragma unroll
-        for (int w = 1; w < NW; w++) {
-          sA1 += cpart[0][w][t]; sA2 += cpart[1][w][t]; sP1 += cpart[2][w][t]; sP2 += cpart[3][w][t];
-        }
+        const double sA1 = cpart[0][0][t], sA2 = cpart[1][0][t], sP1 = cpart[2][0][t], sP2 = cpart[3][0][t];
         if (con) {
           const double ei = d.Einv[r];
           const bool uinf = up > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
@@ -918,33 +961,64 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
       }
     }
     __syncthreads();
+    const long long k1 = d.prof ? clock64() : 0;
     if (t < NQ) {
       double rq = qrow[0][t];
       for (int w = 1; w < RW; w++) rq = t < NQ_MAX ? fmax(rq, qrow[w][t]) : rq + qrow[w][t];
       ll_publish(d.coop_q + (size_t)blockIdx.x * COOP_QS + 2 * t, rq, tag);
     }
     {
-      // quantity q = t % 32 over workgroups g, g + NG, g + 2 NG, ... (g = t / 32), fixed order
-      const int q = t & 31, g = t >> 5;
-      double rq = (q == 4 || q == 5) ? -1.7e308 : 0.0;
-      if (q < NQ) {
-        for (int wg = g; wg < T; wg += NG) {
-          const unsigned long long *p = d.coop_q + (size_t)wg * COOP_QS + 2 * q;
-          unsigned spins = 0;
-          for (;;) {
-            const ll_u4 w = ll_peek(p);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (w.y == tag && w.w == tag) {
-              const double val = __hiloint2double((int)w.z, (int)w.x);
-              rq = q < NQ_MAX ? fmax(rq, val) : rq + val;
-              break;
+      // every workgroup collects the T x NQ partial results (entry e = wg * NQ + q, KC loads in
+      // flight per thread) into LDS ...
+      constexpr int KC = 8;
+      const int E = T * NQ;
+#pragma unroll 1
+      for (int e0 = 0; e0 < E; e0 += COOP_B * KC) {
+        ll_u4 w[KC];
+        bool have[KC];
+        const unsigned long long *src[KC];
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+          const int e = e0 + t + k * COOP_B;
+          have[k] = e >= E;
+          src[k] = d.coop_q + (size_t)(e / NQ) * COOP_QS + 2 * (e % NQ);
+        }
+        unsigned spins = 0;
+        for (;;) {
+#pragma unroll
+          for (int k = 0; k < KC; k++)
+            if (!have[k]) w[k] = ll_peek(src[k]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          bool all = true;
+#pragma unroll
+          for (int k = 0; k < KC; k++)
+            if (!have[k]) {
+              if (w[k].y == tag && w[k].w == tag) {
+                qall[e0 + t + k * COOP_B] = __hiloint2double((int)w[k].z, (int)w[k].x);
+                have[k] = true;
+              } else {
+                all = false;
+              }
             }
-            if (++spins > COOP_SPIN_LIMIT) {
-              s_fail = 1;
-              d.ctrl->pad = 1;
-              break;
-            }
+          if (all) break;
+          if (++spins > COOP_SPIN_LIMIT) {
+            s_fail = 1;
+            d.ctrl->pad = 1;
+            break;
           }
+        }
+      }
+    }
+    __syncthreads();
+    if (s_fail) break;
+    {
+      // ... and reduces them in a fixed order: quantity q = t % 32 over workgroups g, g + NG, ...
+      const int q = t & 31, g = t >> 5;
+      if (q < NQ) {
+        double rq = (q == 4 || q == 5) ? -1.7e308 : 0.0;
+        for (int wg = g; wg < T; wg += NG) {
+          const double val = qall[wg * NQ + q];
+          rq = q < NQ_MAX ? fmax(rq, val) : rq + val;
         }
         qred[g][q] = rq;
       }
@@ -976,13 +1050,17 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
       s_status = st;
     }
     __syncthreads();
+    if (d.prof) {
+      const long long k2 = clock64();
+      ph3 += k1 - k0; ph4 += k2 - k1; nchk++;
+    }
     status = s_status;
     if (status) break;
   }
   if (it > max_iter) it = max_iter;
   if (d.prof && t == 0) {
-    d.prof[4 * blockIdx.x] = ph0; d.prof[4 * blockIdx.x + 1] = ph1; d.prof[4 * blockIdx.x + 2] = ph2;
-    d.prof[4 * blockIdx.x + 3] = it;
+    unsigned long long *o = d.prof + 8 * blockIdx.x;
+    o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = it; o[4] = ph3; o[5] = ph4; o[6] = nchk; o[7] = ph5;
   }
   if (own) {
     if (con) { d.z[r] = sa; d.y[r] = sb; d.dy[r] = delta; d.wh[r] = sw; }
@@ -2493,11 +2571,13 @@ int launch_resident(miosqp_qp_engine *e, int max_iter, int check_every, int fina
 
 void launch_coop(miosqp_qp_engine *e, int max_iter, int check_every, int final_check) {
   const Dev &d = e->d;
+  (void)hipMemsetAsync(d.coop_reg, 0, 64, e->stream);
 #define CO(B, RW, CPT)                                                                                   \
   hipLaunchKernelGGL((k_coop<B, RW, CPT>), dim3(e->coop_T), dim3(B), 0, e->stream, d, max_iter, check_every, \
                      final_check)
-  if (e->coop_cpt == 2) CO(512, 8, 2);
-  else CO(512, 8, 4);
+  if (e->coop_cpt == 4) CO(256, 8, 4);
+  else if (e->coop_cpt == 7) CO(256, 8, 7);
+  else CO(256, 8, 8);
 #undef CO
 }
 
@@ -3097,7 +3177,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         if (wantc && can) {
           e->coop = true;
           e->coop_rw = rw;
-          e->coop_cpt = N <= 1024 ? 2 : 4;
+          e->coop_cpt = N <= 1024 ? 4 : (N <= 1792 ? 7 : 8);
           e->coop_T = T;
           d.ldw = (N + 7) & ~7;
           double *Wd = nullptr;
@@ -3118,6 +3198,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           } else if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_chk, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_q, (size_t)T * COOP_QS + 64);
+          if (!rc) rc = dalloc(e, &d.coop_reg, 64);
           double *Kc = nullptr;
           if (!rc) rc = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
           if (!rc) rc = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
@@ -3373,9 +3454,9 @@ int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, 
   for (int i = 0; i < 20; i++) launch_iteration(e);
   Dev saved = e->d;
   e->d.prof = buf;
-  // which == 2: 1000 iterations of the cooperative solver; per workgroup {reduce, update+publish,
-  // gather} shader clocks of thread 0 and its poll rounds (4 words per workgroup)
-  if (which == 2) launch_coop(e, 1000, 0, 0);
+  // which == 2: 1000 iterations of the cooperative solver; per workgroup 8 words: shader clocks of
+  // thread 0 in {reduce, update+publish, gather}, iterations, {test operands+rows, test norms}, tests, -
+  if (which == 2) launch_coop(e, 1000, 25, 0);
   else if (which == 0) launch_fold_fwd(e); else launch_fold_bwd(e);
   e->d = saved;
   HIPCHK(hipStreamSynchronize(e->stream));
