@@ -192,6 +192,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loop_ms, loop_iters = eng.loop_stats()
+    nodes_here = srch.nodes - n0
     tot = comm.sum([srch.iters - i0, srch.nodes - n0, dt])
     dt_max = dt
     if world > 1:
@@ -230,11 +231,20 @@ def main():
     if rank == 0:
         fs = eng.factor_stats()
         kern = []
-        names = ["k_fold_fwd", "k_fold_bwd"] if fs["fold"] else KERNELS
-        for k, nm in enumerate(names):
-            us, by = eng.time_kernel(k, 300)
-            kern.append(dict(kernel=nm, usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
-        it_us, it_bytes = eng.time_kernel(4, 100)
+        if fs["coop"]:
+            # one launch of k_coop IS one node relaxation (all its iterations and tests): average launch
+            # from the HIP events around the launches of the timed region
+            launches = max(1, nodes_here)
+            us, by = 1e3 * loop_ms / launches, fs["bytes_per_iter"] * loop_iters / launches
+            kern.append(dict(kernel="k_coop", usec=round(us, 3), bytes=round(by), gbs=round(by / us * 1e-3, 1),
+                             launches=launches, iterations_per_launch=round(loop_iters / launches, 1)))
+            it_us, it_bytes = eng.time_kernel(4, 2000)
+        else:
+            names = ["k_fold_fwd", "k_fold_bwd"] if fs["fold"] else KERNELS
+            for k, nm in enumerate(names):
+                us, by = eng.time_kernel(k, 300)
+                kern.append(dict(kernel=nm, usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
+            it_us, it_bytes = eng.time_kernel(4, 100)
         dom = max(kern, key=lambda d: d["usec"])
         roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom["kernel"]),
@@ -257,7 +267,8 @@ def main():
                                         "%d node(s) per rank per step, leaves sharded over %d GPU(s)" %
                                         (cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed, args.wave, world),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
-                               factor_form="product form L^-1 (2 launches/iteration)" if fs["fold"]
+                               factor_form="explicit KKT inverse in registers, cooperative launch per node"
+                               if fs["coop"] else "product form L^-1 (2 launches/iteration)" if fs["fold"]
                                else "L (4 launches/iteration)",
                                qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3)),
                    roofline=roof)

@@ -111,7 +111,7 @@ struct Dev {
   unsigned *coop_tag;            // tag of the last exchange round that completed
   unsigned long long *coop_buf;  // 2 parities x N x {lo32|tag, hi32|tag}
   unsigned long long *coop_chk;  // 2 x coop_half: the test's operands [y ; x] and [proj(dy) ; dx]
-  unsigned long long *coop_q;    // T x COOP_QS: per-workgroup norms / sums of the test
+  unsigned long long *coop_q;    // (256 + 16) x COOP_QS: per-workgroup, then per-group norms / sums of the test
   unsigned *coop_reg;            // start-up registration counter (zeroed before every launch)
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
   int coop_dbg;                  // debug ablation: 1 = no gather
@@ -543,7 +543,8 @@ __device__ __forceinline__ double block_sum(double v, double *lds) {
 struct Norms {
   double pri, nAx, nz, nEv, amax_u, amin_l, dua, nPx, nAty, nq, nPdx, nAtv, ndx, lhs, qdx, xPx, qx;
 };
-__device__ __forceinline__ int decide_status(const Dev &d, const Norms &v, double &obj) {
+template <class P>
+__device__ __forceinline__ int decide_status(const P &d, const Norms &v, double &obj) {
   obj = d.cinv * (0.5 * v.xPx + v.qx);
   const double eps_pri = d.eps_abs + d.eps_rel * fmax(v.nAx, v.nz);
   const double eps_dua = d.eps_abs + d.eps_rel * d.cinv * fmax(fmax(v.nPx, v.nAty), v.nq);
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(256) void k_check_decide(Dev d, int iters_in_chunk)
 // cooperative register-resident solver: the same iteration as ONE exchange per step.
 //   [nu + rho wh ; x~] = W [wh ; rx],  W = K^-1 restricted as in dense_setup.hip (ks_kkt_inverse).
 // Workgroup b keeps rows [b RW, (b+1) RW) of W in registers for the whole launch (thread t holds
-// columns t + k*COOP_B, COOP_B = 256 threads per workgroup: one wave per SIMD, 512 registers each), owns the iterates of those rows, and after every step publishes its RW new
+// columns t + k*COOP_B, COOP_B = 512 threads per workgroup), owns the iterates of those rows, and after every step publishes its RW new
 // entries of [wh ; rx]; every workgroup then gathers the whole vector.  The exchange needs no
 // barrier and no flag: an entry travels as two 8-byte words {low half | tag}, {high half | tag}
 // (8-byte stores are single-copy atomic), written at agent scope into the buffer of the round's
@@ -704,27 +705,270 @@ __device__ __forceinline__ double wave_tsum(double (&v)[RW], int lane) {
 
 constexpr int COOP_QS = 48;  // 8-byte words per workgroup in the norm exchange (NQ entries of 2 words, padded)
 
+// The termination test of the cooperative solver (once per `check_every` iterations).  Returns the
+// status (0 = keep iterating); identical in every workgroup.  Must stay inlined: as a real call it
+// broke at 512 threads per workgroup (ROCm 7.2), and it takes what it reads of Dev by value.
+struct CoopTest {  // what the test reads of Dev, by value (a reference would pin Dev to the stack)
+  unsigned long long *coop_chk, *coop_q;
+  const double *Kc, *Einv, *E, *Dinv, *D;
+  Ctrl *ctrl;
+  int n, M, ldw, coop_stride;
+  double c, cinv, eps_abs, eps_rel, eps_pinf, eps_dinf;
+};
+
 template <int COOP_B, int RW, int CPT>
-__global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_every, int final_check) {
-  if (d.ctrl->done) return;
-  constexpr int NW = COOP_B / 64, NG = COOP_B / 32;
+__device__ __forceinline__ int coop_test(const CoopTest d, unsigned tag, int it, bool own, bool con, double sa,
+                                      double sb, double lo, double up, double delta, int *s_fail) {
+  constexpr int NW = COOP_B / 64;
   static_assert(NQ <= 32, "norm gather layout");
-  // test scratch, two uses that never overlap in time: the operands lv[2][2048] (N <= 2048), then the
-  // gathered partial results qall[T * NQ] (at most 256 workgroups)
+  // scratch with two uses that never overlap in time: the operands lv[2][2048] (N <= 2048), then the
+  // gathered partial results qall[member][NQ]
   __shared__ __attribute__((aligned(16))) double tsc[256 * NQ];
   static_assert(256 * NQ >= 4096, "operand staging");
   double *const qall = tsc;
   double(*const lv)[2048] = reinterpret_cast<double(*)[2048]>(tsc);
-  __shared__ double part[2][NW][RW];
   __shared__ double cpart[4][1][RW];
   __shared__ double qrow[RW][NQ];
-  __shared__ double qred[NG][NQ];
   __shared__ double qres[NQ];
-  __shared__ int s_fail, s_status;
+  __shared__ int s_status;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int M = d.M, N = d.n + d.M, T = gridDim.x;
+  const int r0 = blockIdx.x * RW, r = r0 + t;
+  int slot[CPT];
+#pragma unroll
+  for (int k = 0; k < CPT; k++) {
+    const int c = t + k * COOP_B;
+    slot[k] = (c / RW) * d.coop_stride + 2 * (c % RW);
+  }
+  double vproj = 0.0;
+  if (own && con) {
+    const bool uinf = up > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
+    vproj = delta;
+    if (uinf && linf) vproj = 0.0;
+    else if (uinf) vproj = fmin(vproj, 0.0);
+    else if (linf) vproj = fmax(vproj, 0.0);
+  }
+  // both operands go to LDS; wave w then applies rows 2w, 2w+1 of this workgroup's block of Kc to
+  // them (rows are read once, 16 bytes per lane; a constraint row only has its Abar part).
+  // Columns < M of a variable row are Abar^T, the others Pbar.
+  {
+    // both operands of a column sit next to each other: {y | x, proj(dy) | dx}, polled together
+    bool have[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; k++) have[k] = t + k * COOP_B >= N;
+    unsigned spins = 0;
+    for (;;) {
+      ll_u4 w1[CPT], w2[CPT];
+#pragma unroll
+      for (int k = 0; k < CPT; k++)
+        if (!have[k]) {
+          w1[k] = ll_peek(d.coop_chk + 2 * slot[k]);
+          w2[k] = ll_peek(d.coop_chk + 2 * slot[k] + 2);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bool all = true;
+#pragma unroll
+      for (int k = 0; k < CPT; k++)
+        if (!have[k]) {
+          if (w1[k].y == tag && w1[k].w == tag && w2[k].y == tag && w2[k].w == tag) {
+            lv[0][t + k * COOP_B] = __hiloint2double((int)w1[k].z, (int)w1[k].x);
+            lv[1][t + k * COOP_B] = __hiloint2double((int)w2[k].z, (int)w2[k].x);
+            have[k] = true;
+          } else {
+            all = false;
+          }
+        }
+      if (all) break;
+      if (++spins > COOP_SPIN_LIMIT) {
+        *s_fail = 1;
+        d.ctrl->pad = 3;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (*s_fail) return 0;
+  {
+    constexpr int RPW = RW / NW;  // rows per wave
+    static_assert(RPW * NW == RW && (RPW == 1 || RPW == 2), "rows per wave");
+    double a8[8];  // per row: A^T y, A^T proj(dy), P x (A x), P dx (A dx)
+#pragma unroll
+    for (int k = 0; k < 8; k++) a8[k] = 0.0;
+    const int Ne = N & ~1;
+#pragma unroll
+    for (int h = 0; h < RPW; h++) {
+      const int rr = r0 + RPW * wave + h;
+      if (rr >= N) continue;
+      const double *row = d.Kc + (size_t)rr * d.ldw;
+      double sA1 = 0.0, sA2 = 0.0, sP1 = 0.0, sP2 = 0.0;
+      // all 16-byte pieces of the row are requested before the first is used (N <= 2048: at most 16)
+      constexpr int NCH = 16;
+      const int cbeg = (rr < M ? (M & ~1) : 0) + 2 * lane;
+      double2 a[NCH];
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int c = cbeg + 128 * j;
+        a[j] = c < Ne ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int c = cbeg + 128 * j;
+        if (c >= Ne) continue;
+        const double2 p = *reinterpret_cast<const double2 *>(&lv[0][c]);
+        const double2 s2 = *reinterpret_cast<const double2 *>(&lv[1][c]);
+        if (c < M) { sA1 = fma(a[j].x, p.x, sA1); sA2 = fma(a[j].x, s2.x, sA2); }
+        else { sP1 = fma(a[j].x, p.x, sP1); sP2 = fma(a[j].x, s2.x, sP2); }
+        if (c + 1 < M) { sA1 = fma(a[j].y, p.y, sA1); sA2 = fma(a[j].y, s2.y, sA2); }
+        else { sP1 = fma(a[j].y, p.y, sP1); sP2 = fma(a[j].y, s2.y, sP2); }
+      }
+      if ((N & 1) && lane == 0) {  // last column of an odd width (always a variable column)
+        const double a = row[N - 1];
+        sP1 = fma(a, lv[0][N - 1], sP1);
+        sP2 = fma(a, lv[1][N - 1], sP2);
+      }
+      a8[4 * h] = sA1; a8[4 * h + 1] = sA2; a8[4 * h + 2] = sP1; a8[4 * h + 3] = sP2;
+    }
+    const double ws8 = wave_tsum<8>(a8, lane);
+    if (lane < 8) {
+      const int e = coop_row<8>(lane);  // = 4 h + quantity
+      if ((e >> 2) < RPW) cpart[e & 3][0][RPW * wave + (e >> 2)] = ws8;
+    }
+  }
+  __syncthreads();
+  if (*s_fail) return 0;
+  if (t < RW) {
+#pragma unroll
+    for (int k = 0; k < NQ; k++) qrow[t][k] = (k == 4 || k == 5) ? -1.7e308 : 0.0;
+    if (own) {
+      const double sA1 = cpart[0][0][t], sA2 = cpart[1][0][t], sP1 = cpart[2][0][t], sP2 = cpart[3][0][t];
+      if (con) {
+        const double ei = d.Einv[r];
+        const bool uinf = up > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
+        const double adx = ei * sP2;
+        qrow[t][0] = fabs(ei * (sP1 - sa));
+        qrow[t][1] = fabs(ei * sP1);
+        qrow[t][2] = fabs(ei * sa);
+        qrow[t][3] = fabs(d.E[r] * vproj);
+        qrow[t][4] = uinf ? -1.7e308 : adx;
+        qrow[t][5] = -(linf ? 1.7e308 : adx);
+        qrow[t][13] = up * fmax(vproj, 0.0) + lo * fmin(vproj, 0.0);
+      } else {
+        const int i = r - M;
+        const double di = d.Dinv[i], px = sP1, aty = sA1;
+        qrow[t][6] = fabs(di * (px + sb + aty));
+        qrow[t][7] = fabs(di * px);
+        qrow[t][8] = fabs(di * aty);
+        qrow[t][9] = fabs(di * sb);
+        qrow[t][10] = fabs(di * sP2);
+        qrow[t][11] = fabs(di * sA2);
+        qrow[t][12] = fabs(d.D[i] * delta);
+        qrow[t][14] = sb * delta;
+        qrow[t][15] = sa * px;
+        qrow[t][16] = sb * sa;
+      }
+    }
+  }
+  __syncthreads();
+  if (t < NQ) {
+    double rq = qrow[0][t];
+    for (int w = 1; w < RW; w++) rq = t < NQ_MAX ? fmax(rq, qrow[w][t]) : rq + qrow[w][t];
+    ll_publish(d.coop_q + (size_t)blockIdx.x * COOP_QS + 2 * t, rq, tag);
+  }
+  // Two hops instead of one wide all-gather (an exchange costs by the cache line): workgroup g < NL
+  // reduces the partial results of workgroups g, g + NL, g + 2 NL, ... and publishes the group's;
+  // then everybody gathers the NL group results.  Fixed order, same arithmetic in every workgroup.
+  constexpr int NL = 16, NMEM = 256 / NL;  // at most 256 workgroups
+  auto collect = [&](const unsigned long long *src, int first, int step, int count) {
+    // entries (member m, quantity q), m < count: source workgroup first + m * step; result in qall[m * NQ + q]
+    constexpr int KC = (NMEM * NQ + COOP_B - 1) / COOP_B;
+    ll_u4 w[KC];
+    bool have[KC];
+    const unsigned long long *ptr[KC];
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+      const int e = t + k * COOP_B;
+      have[k] = e >= count * NQ;
+      ptr[k] = src + (size_t)(first + (e / NQ) * step) * COOP_QS + 2 * (e % NQ);
+    }
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int k = 0; k < KC; k++)
+        if (!have[k]) w[k] = ll_peek(ptr[k]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bool all = true;
+#pragma unroll
+      for (int k = 0; k < KC; k++)
+        if (!have[k]) {
+          if (w[k].y == tag && w[k].w == tag) {
+            qall[t + k * COOP_B] = __hiloint2double((int)w[k].z, (int)w[k].x);
+            have[k] = true;
+          } else {
+            all = false;
+          }
+        }
+      if (all) break;
+      if (++spins > COOP_SPIN_LIMIT) {
+        *s_fail = 1;
+        d.ctrl->pad = 4 + (src != d.coop_q);
+        break;
+      }
+    }
+  };
+  const int nl = T < NL ? T : NL;
+  if ((int)blockIdx.x < nl) {
+    const int count = (T - (int)blockIdx.x + nl - 1) / nl;
+    collect(d.coop_q, blockIdx.x, nl, count);
+    __syncthreads();
+    if (t < NQ) {
+      double rq = qall[t];
+      for (int m = 1; m < count; m++) rq = t < NQ_MAX ? fmax(rq, qall[m * NQ + t]) : rq + qall[m * NQ + t];
+      ll_publish(d.coop_q + (size_t)(256 + blockIdx.x) * COOP_QS + 2 * t, rq, tag);
+    }
+    __syncthreads();  // qall is reused below
+  }
+  collect(d.coop_q + (size_t)256 * COOP_QS, 0, 1, nl);
+  __syncthreads();
+  if (*s_fail) return 0;
+  if (t < NQ) {
+    double rq = qall[t];
+    for (int g = 1; g < nl; g++) rq = t < NQ_MAX ? fmax(rq, qall[g * NQ + t]) : rq + qall[g * NQ + t];
+    qres[t] = rq;
+  }
+  __syncthreads();
+  if (t == 0) {
+    Norms nm{qres[0], qres[1], qres[2], qres[3], qres[4], -qres[5], qres[6] * d.cinv, qres[7], qres[8], qres[9],
+             qres[10], qres[11], qres[12], qres[13], qres[14], qres[15], qres[16]};
+    double obj;
+    const int st = decide_status(d, nm, obj);
+    if (blockIdx.x == 0) {
+      Ctrl *c = d.ctrl;
+      c->iter = it;
+      c->pri_res = nm.pri;
+      c->dua_res = nm.dua;
+      c->obj_val = obj;
+      if (st) {
+        c->status = st;
+        c->done = 1;
+      }
+    }
+    s_status = st;
+  }
+  __syncthreads();
+  return s_status;
+}
+
+template <int COOP_B, int RW, int CPT>
+__global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_every, int final_check) {
+  if (d.ctrl->done) return;
+  constexpr int NW = COOP_B / 64;
+  __shared__ __attribute__((aligned(16))) double part[2][RW][NW];
+  __shared__ int s_fail;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int M = d.M, N = d.n + d.M, T = gridDim.x;
   const int r0 = blockIdx.x * RW;
   const unsigned base = *d.coop_tag;
+  const bool prof = d.prof != nullptr;
   double Kr[RW][CPT], v[CPT];
   int slot[CPT];  // word offset of this thread's columns inside an exchange buffer
 #pragma unroll
@@ -747,7 +991,6 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
   // grid is resident before anybody starts to depend on it
   if (t == 0) {
     s_fail = 0;
-    s_status = 0;
     __hip_atomic_fetch_add(d.coop_reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     while (__hip_atomic_load(d.coop_reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)T) {
@@ -801,7 +1044,7 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
       if (all) break;
       if (++spins > COOP_SPIN_LIMIT) {
         s_fail = 1;
-        d.ctrl->pad = 1;
+        d.ctrl->pad = 2;
         break;
       }
     }
@@ -816,7 +1059,7 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
       chk = true;
       to_test = check_every;
     }
-    const long long c0 = d.prof ? clock64() : 0;
+    const long long c0 = prof ? clock64() : 0;
     double acc[RW];
 #pragma unroll
     for (int rw = 0; rw < RW; rw++) {
@@ -826,34 +1069,37 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
       acc[rw] = a;
     }
     const double ws = wave_tsum<RW>(acc, lane);
-    if (lane < RW) part[it & 1][wave][coop_row<RW>(lane)] = ws;
+    if (lane < RW) part[it & 1][coop_row<RW>(lane)][wave] = ws;
     __syncthreads();
     if (s_fail) break;
-    const long long c1 = d.prof ? clock64() : 0;
+    const long long c1 = prof ? clock64() : 0;
     unsigned long long *buf = d.coop_buf + (size_t)(tag & 1u) * d.coop_half;
     double vproj = 0.0;
     if (own) {
-      double s = part[it & 1][0][t];
+      double s = part[it & 1][t][0];
 #pragma unroll
-      for (int w = 1; w < NW; w++) s += part[it & 1][w][t];
+      for (int w = 1; w < NW; w++) s += part[it & 1][t][w];
       double pub;
       if (con) {
-        const double nu = -rho * sw + s;
-        const double zt = sa + rinv * (nu - sb);
+        // z~ = z + (nu - y) / rho with nu = -rho wh + s, relaxed and projected; the entry to publish,
+        // wh+ = z+ - y+ / rho = 2 z+ - (z_r + y / rho), is formed before y+ (shortest path to the store)
+        const double zt = sa + rinv * ((s - rho * sw) - sb);
         const double zr = alpha * zt + (1.0 - alpha) * sa;
-        const double zn = fmin(fmax(zr + rinv * sb, lo), up);
+        const double vv = zr + rinv * sb;
+        const double zn = fmin(fmax(vv, lo), up);
+        pub = 2.0 * zn - vv;
+        ll_publish(buf + my_slot, pub, tag);
         delta = rho * (zr - zn);
         sa = zn;
         sb += delta;
-        sw = zn - rinv * sb;
-        pub = sw;
+        sw = pub;
       } else {
         const double xn = alpha * s + (1.0 - alpha) * sa;
+        pub = sigma * xn - sb;
+        ll_publish(buf + my_slot, pub, tag);
         delta = xn - sa;
         sa = xn;
-        pub = sigma * xn - sb;
       }
-      ll_publish(buf + my_slot, pub, tag);
       if (chk) {  // the test's operands travel with the same round: [y ; x] and [proj(dy) ; dx]
         if (con) {
           const bool uinf = up > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
@@ -862,203 +1108,33 @@ __global__ __launch_bounds__(COOP_B) void k_coop(Dev d, int max_iter, int check_
           else if (uinf) vproj = fmin(vproj, 0.0);
           else if (linf) vproj = fmax(vproj, 0.0);
         }
-        ll_publish(d.coop_chk + my_slot, con ? sb : sa, tag);
-        ll_publish(d.coop_chk + d.coop_half + my_slot, con ? vproj : delta, tag);
+        ll_publish(d.coop_chk + 2 * my_slot, con ? sb : sa, tag);
+        ll_publish(d.coop_chk + 2 * my_slot + 2, con ? vproj : delta, tag);
       }
     }
-    const long long c2 = d.prof ? clock64() : 0;
+    const long long c2 = prof ? clock64() : 0;
     if (!(d.coop_dbg & 1)) gather(buf, tag, v);
-    if (d.prof) {
+    if (prof) {
       ph0 += c1 - c0; ph1 += c2 - c1; ph2 += clock64() - c2;
     }
     if (!chk) continue;
 
     // ---- termination test ----
-    const long long k0 = d.prof ? clock64() : 0;
-    // both operands go to LDS; wave w then applies rows 2w, 2w+1 of this workgroup's block of Kc to
-    // them (rows are read once, 16 bytes per lane; a constraint row only has its Abar part).
-    // Columns < M of a variable row are Abar^T, the others Pbar.
+    const long long k0 = prof ? clock64() : 0;
     {
-      double vv[CPT];
-      gather(d.coop_chk, tag, vv);
-#pragma unroll
-      for (int k = 0; k < CPT; k++)
-        if (t + k * COOP_B < N) lv[0][t + k * COOP_B] = vv[k];
-      gather(d.coop_chk + d.coop_half, tag, vv);
-#pragma unroll
-      for (int k = 0; k < CPT; k++)
-        if (t + k * COOP_B < N) lv[1][t + k * COOP_B] = vv[k];
+      const CoopTest ta{d.coop_chk, d.coop_q, d.Kc, d.Einv, d.E, d.Dinv, d.D, d.ctrl, d.n, d.M, d.ldw, d.coop_stride,
+                        d.c, d.cinv, d.eps_abs, d.eps_rel, d.eps_pinf, d.eps_dinf};
+      status = coop_test<COOP_B, RW, CPT>(ta, tag, it, own, con, sa, sb, lo, up, delta, &s_fail);
     }
-    __syncthreads();
+    if (prof) {
+      ph3 += clock64() - k0;
+      nchk++;
+    }
     if (s_fail) break;
-    {
-      static_assert(RW == 2 * NW, "two rows per wave");
-      double a8[8];  // per row: A^T y, A^T proj(dy), P x (A x), P dx (A dx)
-#pragma unroll
-      for (int k = 0; k < 8; k++) a8[k] = 0.0;
-      const int Ne = N & ~1;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int rr = r0 + 2 * wave + h;
-        if (rr >= N) continue;
-        const double *row = d.Kc + (size_t)rr * d.ldw;
-        double sA1 = 0.0, sA2 = 0.0, sP1 = 0.0, sP2 = 0.0;
-#pragma unroll 4
-        for (int c = (rr < M ? (M & ~1) : 0) + 2 * lane; c < Ne; c += 128) {
-          const double2 a = *reinterpret_cast<const double2 *>(row + c);
-          const double2 p = *reinterpret_cast<const double2 *>(&lv[0][c]);
-          const double2 s2 = *reinterpret_cast<const double2 *>(&lv[1][c]);
-          if (c < M) { sA1 = fma(a.x, p.x, sA1); sA2 = fma(a.x, s2.x, sA2); }
-          else { sP1 = fma(a.x, p.x, sP1); sP2 = fma(a.x, s2.x, sP2); }
-          if (c + 1 < M) { sA1 = fma(a.y, p.y, sA1); sA2 = fma(a.y, s2.y, sA2); }
-          else { sP1 = fma(a.y, p.y, sP1); sP2 = fma(a.y, s2.y, sP2); }
-        }
-        if ((N & 1) && lane == 0) {  // last column of an odd width (always a variable column)
-          const double a = row[N - 1];
-          sP1 = fma(a, lv[0][N - 1], sP1);
-          sP2 = fma(a, lv[1][N - 1], sP2);
-        }
-        a8[4 * h] = sA1; a8[4 * h + 1] = sA2; a8[4 * h + 2] = sP1; a8[4 * h + 3] = sP2;
-      }
-      const double ws8 = wave_tsum<8>(a8, lane);
-      if (lane < 8) {
-        const int e = coop_row<8>(lane);  // = 4 h + quantity
-        cpart[e & 3][0][2 * wave + (e >> 2)] = ws8;
-      }
-    }
-    __syncthreads();
-    if (s_fail) break;
-    if (t < RW) {
-#pragma unroll
-      for (int k = 0; k < NQ; k++) qrow[t][k] = (k == 4 || k == 5) ? -1.7e308 : 0.0;
-      if (own) {
-        const double sA1 = cpart[0][0][t], sA2 = cpart[1][0][t], sP1 = cpart[2][0][t], sP2 = cpart[3][0][t];
-        if (con) {
-          const double ei = d.Einv[r];
-          const bool uinf = up > QP_INFTY * QP_MIN_SCALING, linf = lo < -QP_INFTY * QP_MIN_SCALING;
-          const double adx = ei * sP2;
-          qrow[t][0] = fabs(ei * (sP1 - sa));
-          qrow[t][1] = fabs(ei * sP1);
-          qrow[t][2] = fabs(ei * sa);
-          qrow[t][3] = fabs(d.E[r] * vproj);
-          qrow[t][4] = uinf ? -1.7e308 : adx;
-          qrow[t][5] = -(linf ? 1.7e308 : adx);
-          qrow[t][13] = up * fmax(vproj, 0.0) + lo * fmin(vproj, 0.0);
-        } else {
-          const int i = r - M;
-          const double di = d.Dinv[i], px = sP1, aty = sA1;
-          qrow[t][6] = fabs(di * (px + sb + aty));
-          qrow[t][7] = fabs(di * px);
-          qrow[t][8] = fabs(di * aty);
-          qrow[t][9] = fabs(di * sb);
-          qrow[t][10] = fabs(di * sP2);
-          qrow[t][11] = fabs(di * sA2);
-          qrow[t][12] = fabs(d.D[i] * delta);
-          qrow[t][14] = sb * delta;
-          qrow[t][15] = sa * px;
-          qrow[t][16] = sb * sa;
-        }
-      }
-    }
-    __syncthreads();
-    const long long k1 = d.prof ? clock64() : 0;
-    if (t < NQ) {
-      double rq = qrow[0][t];
-      for (int w = 1; w < RW; w++) rq = t < NQ_MAX ? fmax(rq, qrow[w][t]) : rq + qrow[w][t];
-      ll_publish(d.coop_q + (size_t)blockIdx.x * COOP_QS + 2 * t, rq, tag);
-    }
-    {
-      // every workgroup collects the T x NQ partial results (entry e = wg * NQ + q, KC loads in
-      // flight per thread) into LDS ...
-      constexpr int KC = 8;
-      const int E = T * NQ;
-#pragma unroll 1
-      for (int e0 = 0; e0 < E; e0 += COOP_B * KC) {
-        ll_u4 w[KC];
-        bool have[KC];
-        const unsigned long long *src[KC];
-#pragma unroll
-        for (int k = 0; k < KC; k++) {
-          const int e = e0 + t + k * COOP_B;
-          have[k] = e >= E;
-          src[k] = d.coop_q + (size_t)(e / NQ) * COOP_QS + 2 * (e % NQ);
-        }
-        unsigned spins = 0;
-        for (;;) {
-#pragma unroll
-          for (int k = 0; k < KC; k++)
-            if (!have[k]) w[k] = ll_peek(src[k]);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          bool all = true;
-#pragma unroll
-          for (int k = 0; k < KC; k++)
-            if (!have[k]) {
-              if (w[k].y == tag && w[k].w == tag) {
-                qall[e0 + t + k * COOP_B] = __hiloint2double((int)w[k].z, (int)w[k].x);
-                have[k] = true;
-              } else {
-                all = false;
-              }
-            }
-          if (all) break;
-          if (++spins > COOP_SPIN_LIMIT) {
-            s_fail = 1;
-            d.ctrl->pad = 1;
-            break;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (s_fail) break;
-    {
-      // ... and reduces them in a fixed order: quantity q = t % 32 over workgroups g, g + NG, ...
-      const int q = t & 31, g = t >> 5;
-      if (q < NQ) {
-        double rq = (q == 4 || q == 5) ? -1.7e308 : 0.0;
-        for (int wg = g; wg < T; wg += NG) {
-          const double val = qall[wg * NQ + q];
-          rq = q < NQ_MAX ? fmax(rq, val) : rq + val;
-        }
-        qred[g][q] = rq;
-      }
-    }
-    __syncthreads();
-    if (s_fail) break;
-    if (t < NQ) {
-      double rq = qred[0][t];
-      for (int g = 1; g < NG; g++) rq = t < NQ_MAX ? fmax(rq, qred[g][t]) : rq + qred[g][t];
-      qres[t] = rq;
-    }
-    __syncthreads();
-    if (t == 0) {
-      Norms nm{qres[0], qres[1], qres[2], qres[3], qres[4], -qres[5], qres[6] * d.cinv, qres[7], qres[8], qres[9],
-               qres[10], qres[11], qres[12], qres[13], qres[14], qres[15], qres[16]};
-      double obj;
-      const int st = decide_status(d, nm, obj);
-      if (blockIdx.x == 0) {
-        Ctrl *c = d.ctrl;
-        c->iter = it;
-        c->pri_res = nm.pri;
-        c->dua_res = nm.dua;
-        c->obj_val = obj;
-        if (st) {
-          c->status = st;
-          c->done = 1;
-        }
-      }
-      s_status = st;
-    }
-    __syncthreads();
-    if (d.prof) {
-      const long long k2 = clock64();
-      ph3 += k1 - k0; ph4 += k2 - k1; nchk++;
-    }
-    status = s_status;
     if (status) break;
   }
   if (it > max_iter) it = max_iter;
-  if (d.prof && t == 0) {
+  if (prof && t == 0) {
     unsigned long long *o = d.prof + 8 * blockIdx.x;
     o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = it; o[4] = ph3; o[5] = ph4; o[6] = nchk; o[7] = ph5;
   }
@@ -2575,9 +2651,8 @@ void launch_coop(miosqp_qp_engine *e, int max_iter, int check_every, int final_c
 #define CO(B, RW, CPT)                                                                                   \
   hipLaunchKernelGGL((k_coop<B, RW, CPT>), dim3(e->coop_T), dim3(B), 0, e->stream, d, max_iter, check_every, \
                      final_check)
-  if (e->coop_cpt == 4) CO(256, 8, 4);
-  else if (e->coop_cpt == 7) CO(256, 8, 7);
-  else CO(256, 8, 8);
+  if (e->coop_cpt == 2) CO(512, 8, 2);
+  else CO(512, 8, 4);
 #undef CO
 }
 
@@ -2678,7 +2753,7 @@ int finish_and_fetch(miosqp_qp_engine *e, int node, double *x_out, double *y_out
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   if (e->h_ctrl->pad) {
-    g_err = "cooperative solver: exchange timed out (workgroups not co-resident?)";
+    g_err = "cooperative solver: exchange timed out (workgroups not co-resident?), stage " + std::to_string(e->h_ctrl->pad);
     return MIOSQP_EHIP;
   }
   memcpy(x_out, e->h_out, sizeof(double) * e->n);
@@ -3177,7 +3252,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         if (wantc && can) {
           e->coop = true;
           e->coop_rw = rw;
-          e->coop_cpt = N <= 1024 ? 4 : (N <= 1792 ? 7 : 8);
+          e->coop_cpt = N <= 1024 ? 2 : 4;
           e->coop_T = T;
           d.ldw = (N + 7) & ~7;
           double *Wd = nullptr;
@@ -3197,7 +3272,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
             d.coop_buf = (unsigned long long *)pb;
           } else if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_chk, 2 * d.coop_half + 64);
-          if (!rc) rc = dalloc(e, &d.coop_q, (size_t)T * COOP_QS + 64);
+          if (!rc) rc = dalloc(e, &d.coop_q, (size_t)(256 + 16) * COOP_QS + 64);
           if (!rc) rc = dalloc(e, &d.coop_reg, 64);
           double *Kc = nullptr;
           if (!rc) rc = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
@@ -3531,10 +3606,17 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
       default: launch_iteration(e); break;
     }
   };
-  for (int i = 0; i < 5; i++) one();
-  HIPCHK(hipEventRecord(e->ev0, e->stream));
-  for (int i = 0; i < reps; i++) one();
-  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  if (e->coop && which == 4) {  // `reps` iterations of the cooperative solver in ONE launch, no tests
+    launch_coop(e, 5, 0, 0);
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    launch_coop(e, reps, 0, 0);
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+  } else {
+    for (int i = 0; i < 5; i++) one();
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    for (int i = 0; i < reps; i++) one();
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
