@@ -347,17 +347,22 @@ def test_batched_search_finds_the_same_optimum():
     np.testing.assert_array_equal(out[0][2][ii], out[1][2][ii])
 
 
-@pytest.mark.parametrize("fold,resident", [(0, 0), (1, 0), (1, 1)])
-def test_both_factor_forms_match_oracle(oracle_mod, fold, resident):
+FORMS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 0, 1)]
+
+
+@pytest.mark.parametrize("fold,resident,coop", FORMS)
+def test_both_factor_forms_match_oracle(oracle_mod, fold, resident, coop):
     """fold=0: factor form L (4 kernels per iteration); fold=1: product form L^-1 (2 kernels);
-    resident=1: the whole solve in one LDS-resident workgroup."""
+    resident=1: the whole solve in one LDS-resident workgroup; coop=1: the whole solve in one
+    cooperative launch, explicit KKT inverse in registers, one exchange per iteration."""
     from miosqp_amd import qp
     pr = problems.random_miqp(60, 120, 30, seed=11)
     A, l, u = problems.extended(pr)
     g, o = qp.OSQP(), oracle_mod.OSQP()
-    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, **problems.QP_SETTINGS)
+    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, coop=coop, **problems.QP_SETTINGS)
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
-    assert g.factor_stats()["fold"] == bool(fold) and g.factor_stats()["resident"] == bool(resident)
+    fs = g.factor_stats()
+    assert (fs["fold"], fs["resident"], fs["coop"]) == (bool(fold), bool(resident), bool(coop))
     rng = np.random.RandomState(3)
     x0, y0 = rng.randn(60), rng.randn(A.shape[0])
     for k in (1, 3, 40):
@@ -465,9 +470,9 @@ def test_setup_rejects_bad_input():
         qp.OSQP().setup(P, np.zeros(3), spa.csc_matrix(np.eye(3)), -np.ones(3), np.ones(3), adaptive_rho=True)
 
 
-@pytest.mark.parametrize("fold,resident", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("fold,resident,coop", FORMS)
 @pytest.mark.parametrize("max_iter,check", [(60, 25), (50, 0), (30, 7), (25, 25), (3, 1)])
-def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, max_iter, check):
+def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, coop, max_iter, check):
     """MAX_ITER_REACHED, a tail chunk shorter than the cadence, cadence 1, and the test switched off:
     status, iteration count and iterates equal the oracle's in every engine form."""
     from miosqp_amd import qp
@@ -475,7 +480,7 @@ def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, max_iter,
     A, l, u = problems.extended(pr)
     kw = dict(problems.QP_SETTINGS, max_iter=max_iter, check_termination=check, eps_abs=1e-9, eps_rel=1e-9)
     g, o = qp.OSQP(), oracle_mod.OSQP()
-    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, **kw)
+    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, coop=coop, **kw)
     o.setup(pr["P"], pr["q"], A, l, u, **kw)
     x0, y0 = np.full(40, 0.3), np.zeros(A.shape[0])
     g.warm_start(x=x0, y=y0)
@@ -487,7 +492,7 @@ def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, max_iter,
     # loose tolerances: converges at the first test that passes; same iteration as the oracle
     kw2 = dict(problems.QP_SETTINGS, max_iter=4000, check_termination=max(check, 1))
     g2, o2 = qp.OSQP(), oracle_mod.OSQP()
-    g2.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, **kw2)
+    g2.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, coop=coop, **kw2)
     o2.setup(pr["P"], pr["q"], A, l, u, **kw2)
     g2.warm_start(x=x0, y=y0)
     o2.warm_start(x=x0, y=y0)
@@ -538,3 +543,94 @@ def test_device_setup_matches_host_setup(oracle_mod, n, m, p, seed):
             assert rel(a, b) <= ITER_TOL
     for a, b in zip(outs[0], outs[1]):
         assert rel(a, b) <= 1e-11
+
+
+def _infeasible_variants(pr):
+    """(P, q, A, l, u, expected status) built from a random instance: a duplicated constraint row with a
+    disjoint interval (primal infeasible), a free variable with zero curvature and a linear cost
+    (dual infeasible)."""
+    import scipy.sparse as spa
+    A, l, u = problems.extended(pr)
+    A = spa.csc_matrix(A)
+    n = A.shape[1]
+    row0 = A.getrow(0)
+    Ap = spa.vstack([A, row0]).tocsc()
+    lp, up = np.append(l, u[0] + 1.0), np.append(u, u[0] + 2.0)
+    yield pr["P"], pr["q"], Ap, lp, up, -3
+    k = [i for i in range(n) if i not in set(pr["i_idx"])][0]
+    keep = spa.diags([0.0 if i == k else 1.0 for i in range(n)])
+    Pd = (keep @ spa.csc_matrix(pr["P"]) @ keep).tocsc()
+    Ad = (A @ keep).tocsc()
+    qd = np.array(pr["q"], dtype=float)
+    qd[k] = 1.0
+    yield Pd, qd, Ad, l, u, -4
+
+
+@pytest.mark.parametrize("coop", [0, 1])
+@pytest.mark.parametrize("n,m,p,seed", [(60, 120, 30, 5), (300, 600, 150, 6)])
+def test_certificates_on_random_instances(oracle_mod, n, m, p, seed, coop):
+    """Infeasibility detection (OSQP paper sec. 3.4) on instances large enough for every engine form;
+    status, iteration and the normalised certificate equal the oracle's."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    for (P, q, A, l, u, code) in _infeasible_variants(pr):
+        g, o = qp.OSQP(), oracle_mod.OSQP()
+        g.setup(P, q, A, l, u, coop=coop, resident=0, **problems.QP_SETTINGS)
+        o.setup(P, q, A, l, u, **problems.QP_SETTINGS)
+        assert g.factor_stats()["coop"] == bool(coop)
+        z0, w0 = np.zeros(A.shape[1]), np.zeros(A.shape[0])
+        g.warm_start(x=z0, y=w0)
+        o.warm_start(x=z0, y=w0)
+        rg, ro = g.solve(), o.solve()
+        assert ro.info.status_val == code
+        assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
+        np.testing.assert_allclose(rg.x, ro.x, rtol=1e-6, atol=1e-8, equal_nan=True)
+        np.testing.assert_allclose(rg.y, ro.y, rtol=1e-6, atol=1e-8, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,m,p,seed", [(100, 150, 40, 7), (300, 500, 150, 8), (500, 1000, 250, 0)])
+def test_cooperative_solver_equals_two_kernel_form(oracle_mod, n, m, p, seed):
+    """The cooperative launch (auto for 256 <= n + M <= 2048) against the product-form kernels on a chain
+    of node relaxations: same status and iteration count, solutions within SOL_TOL, identical digests; and
+    against the oracle on raw iterates.  Covers both register layouts (n + M <= 1024 and above) and many
+    consecutive launches (the exchange tags run on across launches)."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    A, l, u = problems.extended(pr)
+    M = A.shape[0]
+    eng = []
+    for coop in (1, 0):
+        g = qp.OSQP()
+        g.setup(pr["P"], pr["q"], A, l, u, coop=coop, resident=0, **problems.QP_SETTINGS)
+        assert g.factor_stats()["coop"] == bool(coop)
+        g.set_integer_rows(pr["i_idx"], pr["A"].shape[0])
+        g.set_root(l, u, 1e-3, 1e-3)
+        eng.append(g)
+    o = oracle_mod.OSQP()
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    rng = np.random.RandomState(seed)
+    x0, y0 = rng.randn(n), rng.randn(M)
+    for k in (1, 2, 26, 75):
+        o.warm_start(x=x0, y=y0)
+        o.iterate(k)
+        xo, zo, yo = o.iterates()
+        eng[0].warm_start(x=x0, y=y0)
+        xg, zg, yg = eng[0].debug_iterate(k)
+        assert rel(xg, xo) <= ITER_TOL and rel(zg, zo) <= ITER_TOL and rel(yg, yo) <= ITER_TOL, k
+    x, y = np.zeros(n), np.zeros(M)
+    lo, hi = l.copy(), u.copy()
+    for depth in range(6):
+        ra, rb = (g.solve_node(lo, hi, x, y) for g in eng)
+        assert (ra.status_val, ra.iter) == (rb.status_val, rb.iter), depth
+        if ra.status_val not in (1, -2):
+            break
+        assert rel(ra.x, rb.x) <= SOL_TOL and rel(ra.y, rb.y) <= SOL_TOL
+        assert abs(ra.lower - rb.lower) <= 1e-9 * max(1.0, abs(rb.lower))
+        assert (ra.digest.int_inf, ra.digest.nextvar) == (rb.digest.int_inf, rb.digest.nextvar)
+        if ra.digest.int_inf == 0:
+            break
+        # branch down on the chosen variable, as Workspace.branch does (workspace.py:143-203)
+        j = pr["A"].shape[0] + ra.digest.nextvar
+        hi = hi.copy()
+        hi[j] = np.floor(ra.x[pr["i_idx"][ra.digest.nextvar]])
+        x, y = ra.x, ra.y
