@@ -39,8 +39,11 @@ def pmc_traffic(kernel):
     if not files:
         return None
     try:
-        rec = json.load(open(files[-1]))["kernels"].get(kernel)
-        return None if rec is None else rec["traffic_bytes"]
+        kernels = json.load(open(files[-1]))["kernels"]
+        for name in sorted(kernels):  # template instances are listed as "name<...>"
+            if name == kernel or name.startswith(kernel + "<"):
+                return kernels[name]["traffic_bytes"]
+        return None
     except Exception:
         return None
 

@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Merge the FETCH_SIZE and WRITE_SIZE passes (tools/rocpd_pmc.py output) into profiles/rNN_pmc_traffic.json.
+
+    python tools/pmc_merge.py fetch.json write.json "<command line profiled>" > profiles/r01_pmc_traffic.json
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reads exactly half of the bytes of a wide
+coalesced streaming read, so it is doubled; WRITE_SIZE is taken as is.  Both counters are in KiB.
+"""
+import json
+import sys
+
+
+def main():
+    fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) -- "
+                     + sys.argv[3] + "; MI355X; summarised on the GPU box by tools/rocpd_pmc.py + tools/pmc_merge.py",
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (mean over all dispatches of the kernel)",
+           "correction": "gfx950: FETCH_SIZE reads exactly 1/2 of the bytes of a wide coalesced streaming read "
+                         "(MI355X_MICROARCH.md, HBM section) -> fetch is doubled; WRITE_SIZE is taken as is",
+           "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, {}).get("FETCH_SIZE")
+        w = write.get(k, {}).get("WRITE_SIZE")
+        rec = {"dispatches": (f or w)["dispatches"]}
+        if f:
+            rec["FETCH_SIZE_KiB"] = round(f["mean"], 3)
+        if w:
+            rec["WRITE_SIZE_KiB"] = round(w["mean"], 3)
+        rec["traffic_bytes"] = int(round(1024 * (2 * (f["mean"] if f else 0.0) + (w["mean"] if w else 0.0))))
+        out["kernels"][k] = rec
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
