@@ -146,6 +146,21 @@ __device__ __forceinline__ double dpp_get(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+// v + (v of lane ^ 16) and v + (v of lane ^ 32) without the LDS crossbar: gfx950's permlane swaps exchange
+// the odd 16-lane rows (upper 32 lanes) of one register with the even rows (lower lanes) of another; with
+// both holding v, the two results are the two halves of every pair
+__device__ __forceinline__ double add_xor16(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double add_xor32(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
 // butterfly sum over aligned groups of W lanes (W a power of two), small strides first; fixed order
 template <int NV>
 __device__ __forceinline__ void group_sum(double (&v)[NV], int W) {
@@ -153,13 +168,13 @@ __device__ __forceinline__ void group_sum(double (&v)[NV], int W) {
   if (W > MIN) {                                                                     \
     _Pragma("unroll") for (int k = 0; k < NV; k++) v[k] += dpp_get<CTRL>(v[k]);      \
   }
-#define GS_SHFL(MIN, OFF)                                                            \
+#define GS_SWAP(MIN, FN)                                                             \
   if (W > MIN) {                                                                     \
-    _Pragma("unroll") for (int k = 0; k < NV; k++) v[k] += __shfl_xor(v[k], OFF, 64); \
+    _Pragma("unroll") for (int k = 0; k < NV; k++) v[k] = FN(v[k]);                   \
   }
-  GS_DPP(1, 0xB1) GS_DPP(2, 0x4E) GS_DPP(4, 0x141) GS_DPP(8, 0x140) GS_SHFL(16, 16) GS_SHFL(32, 32)
+  GS_DPP(1, 0xB1) GS_DPP(2, 0x4E) GS_DPP(4, 0x141) GS_DPP(8, 0x140) GS_SWAP(16, add_xor16) GS_SWAP(32, add_xor32)
 #undef GS_DPP
-#undef GS_SHFL
+#undef GS_SWAP
 }
 
 template <int TPR, int NV>
@@ -698,9 +713,7 @@ __device__ __forceinline__ double wave_tsum(double (&v)[RW], int lane) {
     v[0] += dpp_get<0x140>(v[0]);
   }
 #undef HALVE
-  v[0] += __shfl_xor(v[0], 16, 64);
-  v[0] += __shfl_xor(v[0], 32, 64);
-  return v[0];
+  return add_xor32(add_xor16(v[0]));
 }
 
 constexpr int COOP_QS = 48;  // 8-byte words per workgroup in the norm exchange (NQ entries of 2 words, padded)
