@@ -67,7 +67,7 @@ typedef struct miosqp_qp_settings {
                                 the inverse of its triangular factor computed on the GPU at setup */
   int32_t coop;              /* -1 auto, 0 off, 1 on: cooperative register-resident solver -- the explicit KKT
                                 inverse (n+M)^2 spread over the register files of up to one workgroup per
-                                CU, ONE exchange per iteration (needs the product form and n+M <= 2048) */
+                                CU, ONE exchange per iteration (n+M <= 2048; auto from n+M = 64 on) */
   int32_t reserved[2];
 } miosqp_qp_settings;
 

@@ -590,7 +590,7 @@ def test_certificates_on_random_instances(oracle_mod, n, m, p, seed, coop):
 
 @pytest.mark.parametrize("n,m,p,seed", [(100, 150, 40, 7), (300, 500, 150, 8), (500, 1000, 250, 0)])
 def test_cooperative_solver_equals_two_kernel_form(oracle_mod, n, m, p, seed):
-    """The cooperative launch (auto for 256 <= n + M <= 2048) against the product-form kernels on a chain
+    """The cooperative launch (auto for 64 <= n + M <= 2048) against the product-form kernels on a chain
     of node relaxations: same status and iteration count, solutions within SOL_TOL, identical digests; and
     against the oracle on raw iterates.  Covers both register layouts (n + M <= 1024 and above) and many
     consecutive launches (the exchange tags run on across launches)."""
