@@ -1,0 +1,54 @@
+"""The sharded search at world sizes 4 and 8 (threads of one process, CPU oracle as the engine): every rank
+ends with the same incumbent, it is the sequential optimum, leaves are dealt once, ranks that run dry are
+fed, and the waves terminate."""
+import threading
+
+import numpy as np
+import pytest
+
+import digest_backend
+from miosqp_amd import bnb, dist, problems
+from thread_comm import ThreadComm, ThreadWorld
+
+
+def _run(world, pr, per_rank, batched):
+    tw = ThreadWorld(world)
+    out = [None] * world
+    err = []
+
+    def main(rank):
+        try:
+            m = bnb.MIOSQP(backend=digest_backend)
+            m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                    dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+            s = dist.ShardedSearch(m, ThreadComm(tw, rank))
+            s.run(nodes_per_rank=per_rank, batched=batched)
+            out[rank] = dict(upper=m.work.upper_glob, x=np.array(m.work.x), nodes=s.nodes, moved=s.moved,
+                             status=m.work.status, leaves=len(m.work.leaves))
+        except Exception as e:  # a dead rank would leave the others at a barrier
+            err.append(e)
+            tw.bar.abort()
+
+    th = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not err, err
+    return out
+
+
+@pytest.mark.parametrize("world,per_rank,batched", [(4, 1, False), (8, 2, False), (4, 4, True)])
+def test_many_ranks_agree_with_the_sequential_search(world, per_rank, batched):
+    pr = problems.random_miqp(30, 150, 15, seed=4)
+    ref = bnb.MIOSQP(backend=digest_backend)
+    ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+              dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    r = ref.solve()
+    out = _run(world, pr, per_rank, batched)
+    ii = pr["i_idx"]
+    for o in out:
+        assert o["status"] == bnb.MI_SOLVED and o["leaves"] == 0
+        assert o["upper"] == out[0]["upper"]
+        np.testing.assert_array_equal(o["x"], out[0]["x"])
+        assert abs(o["upper"] - r.upper_glob) <= 1e-3 * max(1.0, abs(r.upper_glob))
+        np.testing.assert_array_equal(o["x"][ii], r.x[ii])
+    assert sum(o["nodes"] for o in out) >= 1

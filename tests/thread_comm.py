@@ -1,0 +1,56 @@
+"""In-process stand-in for a torch.distributed group: W ranks as threads sharing one object.  Same
+interface as miosqp_amd.dist.TorchComm (exchange / leaf_counts / move / sum / barrier); lets the CPU suite
+and tools/sim_scaling.py run the sharded search at world sizes 4 and 8 without processes."""
+import threading
+
+import numpy as np
+
+
+class ThreadWorld(object):
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world, timeout=300)
+        self.slots = [None] * world
+
+
+class ThreadComm(object):
+    def __init__(self, tw, rank):
+        self.tw, self.rank, self.world = tw, rank, tw.world
+        self._counts = None
+
+    def _all(self, obj):
+        tw = self.tw
+        tw.slots[self.rank] = obj
+        tw.bar.wait()
+        out = list(tw.slots)
+        tw.bar.wait()
+        return out
+
+    def exchange(self, value, x, nleaves, have=None):
+        tab = self._all((value, nleaves, None if x is None else np.array(x)))
+        self._counts = [int(t[1]) for t in tab]
+        vals = np.array([t[0] for t in tab])
+        owner = int(np.argmin(vals))
+        best = float(vals[owner])
+        total = sum(self._counts)
+        prev = float(np.max(vals)) if have is None else have
+        if not np.isfinite(best) or not best < prev:
+            return best, owner, None, total
+        return best, owner, np.array(tab[owner][2]), total
+
+    def incumbent(self, value, x):
+        best, owner, xb, _ = self.exchange(value, x, 0)
+        return best, owner, (x if xb is None else xb)
+
+    def leaf_counts(self):
+        return list(self._counts)
+
+    def move(self, arr, size, src):
+        tab = self._all(None if arr is None else np.array(arr))
+        return np.array(tab[src])
+
+    def sum(self, arr):
+        return np.sum(self._all(np.asarray(arr, dtype=np.float64)), axis=0)
+
+    def barrier(self):
+        self.tw.bar.wait()
