@@ -185,6 +185,7 @@ class Workspace(object):
         self.osqp_iter = 0
         self.osqp_iter_avg = 0
         self.lower_glob = -np.inf
+        self.defer_lower = False
         self.status = MI_UNSOLVED
 
     def _make_root(self):
@@ -297,6 +298,12 @@ class Workspace(object):
         self.add_left(leaf)
         self.add_right(leaf)
 
+    def update_lower_glob(self):
+        # workspace.py:334: after every branching; a wave defers it to its end (`defer_lower`), the value is
+        # only reported, never used for a decision
+        if not self.defer_lower:
+            self.lower_glob = min(lf.lower for lf in self.leaves)
+
     def bound_and_branch(self, leaf):
         # workspace.py:282-334
         self.osqp_iter += leaf.num_iter
@@ -323,7 +330,7 @@ class Workspace(object):
             leaf.nextvar_idx = self.data.i_idx[dg.nextvar]
             self.add_left(leaf)
             self.add_right(leaf)
-            self.lower_glob = min(lf.lower for lf in self.leaves)
+            self.update_lower_glob()
             return
         if self.is_int_feas(leaf.x, leaf):
             self.x = leaf.x
@@ -338,7 +345,7 @@ class Workspace(object):
                 self.x = x_int
                 self.prune()
         self.branch(leaf)
-        self.lower_glob = min(lf.lower for lf in self.leaves)
+        self.update_lower_glob()
 
     # -- results -------------------------------------------------------------------------
     def get_return_status(self):

@@ -167,10 +167,14 @@ class ShardedSearch(object):
             w.leaves = [lf for i, lf in enumerate(w.leaves) if i not in taken]
         if wave:
             w.solve_wave(wave)
+            w.defer_lower = True  # one pass over the leaves per wave instead of one per node
             for leaf in wave:
                 w.bound_and_branch(leaf)
                 w.iter_num += 1
                 self._count(leaf)
+            w.defer_lower = False
+            if w.leaves:
+                w.lower_glob = min(lf.lower for lf in w.leaves)
         return len(wave)
 
     def expand_until(self, n_leaves, max_nodes=10 ** 9):
