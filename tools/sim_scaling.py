@@ -15,7 +15,9 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import digest_backend
 from miosqp_amd import bnb, dist, problems
 
+import os
 T_ITER, T_NODE, T_SYNC = 2.83e-6, 170e-6, 60e-6
+LAG = int(os.environ.get("SIM_LAG", "0"))  # model of a non-blocking exchange: wait only for the one LAG steps back
 
 
 class SimWorld(object):
@@ -25,11 +27,13 @@ class SimWorld(object):
         self.slots = [None] * world
         self.clock = [0.0] * world
         self.busy = [0.0] * world
+        self.hist = []  # per exchange: the latest arrival over ranks
 
 
 class SimComm(object):
     def __init__(self, sw, rank):
         self.sw, self.rank, self.world = sw, rank, sw.world
+        self.step_no = 0
 
     def _all(self, obj):
         sw = self.sw
@@ -42,7 +46,15 @@ class SimComm(object):
     def exchange(self, value, x, nleaves, have=None):
         sw = self.sw
         tab = self._all((value, nleaves, x, sw.clock[self.rank]))
-        sw.clock[self.rank] = max(t[3] for t in tab) + T_SYNC
+        if self.rank == 0:
+            sw.hist.append(max(t[3] for t in tab))
+        sw.bar.wait()
+        k = self.step_no - LAG
+        self.step_no += 1
+        if LAG == 0:
+            sw.clock[self.rank] = sw.hist[-1] + T_SYNC
+        else:
+            sw.clock[self.rank] = max(sw.clock[self.rank], sw.hist[k] if k >= 0 else 0.0) + 0.25 * T_SYNC
         self._counts = [int(t[1]) for t in tab]
         vals = np.array([t[0] for t in tab])
         owner = int(np.argmin(vals))
@@ -103,8 +115,10 @@ def main():
     base = None
     print("cfg %s seed %d instances %d; model: %.2f us/iter, %.0f us/node, %.0f us/exchange" % (
         cfg, seed, instances, T_ITER * 1e6, T_NODE * 1e6, T_SYNC * 1e6))
-    for world in (1, 2, 4, 8):
-        for wave in ((1,) if world == 1 else (1, 4, 16)):
+    worlds = [int(v) for v in os.environ.get("SIM_WORLDS", "1,2,4,8").split(",")]
+    waves = [int(v) for v in os.environ.get("SIM_WAVES", "1,4,16").split(",")]
+    for world in worlds:
+        for wave in ((1,) if world == 1 else waves):
             sw = SimWorld(world)
             out = [None] * world
             th = [threading.Thread(target=rank_main, args=(sw, r, prob, wave, instances, seed, out)) for r in range(world)]
