@@ -634,3 +634,34 @@ def test_cooperative_solver_equals_two_kernel_form(oracle_mod, n, m, p, seed):
         hi = hi.copy()
         hi[j] = np.floor(ra.x[pr["i_idx"][ra.digest.nextvar]])
         x, y = ra.x, ra.y
+
+
+@pytest.mark.parametrize("n,m,p", [(20, 39, 4), (20, 40, 4), (21, 38, 6), (300, 600, 124), (300, 600, 125), (600, 1100, 348),
+                                    (600, 1100, 349), (700, 1000, 341), (1000, 40, 8), (30, 900, 20)])
+def test_engine_form_boundaries(oracle_mod, n, m, p):
+    """Sizes on the edges of the automatic choice (n+M = 64: LDS-resident below, cooperative from there;
+    1024 / 1025: two register layouts; 2041…2048: the last full grid of 256 workgroups; 2049: back to the
+    two-kernel form) and lopsided shapes (few constraints, few variables, odd widths)."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(n, m, p, seed=n + m)
+    A, l, u = problems.extended(pr)
+    N = n + A.shape[0]
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    fs = g.factor_stats()
+    assert fs["coop"] == (64 <= N <= 2048) and fs["resident"] == (N < 64), (N, fs)
+    rng = np.random.RandomState(N)
+    x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(A.shape[0])
+    for k in (1, 27):
+        g.warm_start(x=x0, y=y0)
+        o.warm_start(x=x0, y=y0)
+        xg, zg, yg = g.debug_iterate(k)
+        o.iterate(k)
+        xo, zo, yo = o.iterates()
+        assert rel(xg, xo) <= ITER_TOL and rel(zg, zo) <= ITER_TOL and rel(yg, yo) <= ITER_TOL, (N, k)
+    g.warm_start(x=x0, y=y0)
+    o.warm_start(x=x0, y=y0)
+    rg, ro = g.solve(), o.solve()
+    assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), N
+    assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL
