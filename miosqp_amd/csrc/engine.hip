@@ -114,7 +114,7 @@ struct Dev {
   unsigned long long *coop_q;    // (256 + 16) x COOP_QS: per-workgroup, then per-group norms / sums of the test
   unsigned *coop_reg;            // start-up registration counter (zeroed before every launch)
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
-  int coop_dbg;                  // debug ablation: 1 = no gather
+  int coop_dbg;                  // debug ablation: 1 = no gather, 2 = no nap before the first poll of a round
   int coop_stride;               // 8-byte words between the blocks of consecutive workgroups (>= 2 RW)
   size_t coop_half;              // words per parity
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
