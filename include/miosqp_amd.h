@@ -165,7 +165,8 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
 /* sizes of the factor: out[0]=nnz(L) strict (panel + tail), out[1]=nnz panel, out[2]=tail order,
  * out[3]=algorithmic bytes per ADMM iteration (SURVEY.md sec. 8d formula), out[4..6] threads per
  * row of the panel/tail kernels, out[7] bit 0 = product-form factor in use, bit 1 = LDS-resident solver in use,
- * bit 2 = dense setup stages ran on the device */
+ * bit 2 = dense setup stages ran on the device, bit 3 = cooperative solver in use, bits 8..15 = its calibrated
+ * poll delay (64-clock units) */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
 
 /* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's

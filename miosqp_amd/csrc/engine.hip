@@ -114,7 +114,8 @@ struct Dev {
   unsigned long long *coop_q;    // (256 + 16) x COOP_QS: per-workgroup, then per-group norms / sums of the test
   unsigned *coop_reg;            // start-up registration counter (zeroed before every launch)
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
-  int coop_dbg;                  // debug ablation: 1 = no gather, 2 = no nap before the first poll of a round
+  int coop_dbg;                  // debug ablation: 1 = no gather
+  int coop_nap;                  // 64-clock naps between publishing and the first poll of a round (calibrated)
   int coop_stride;               // 8-byte words between the blocks of consecutive workgroups (>= 2 RW)
   size_t coop_half;              // words per parity
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
@@ -461,6 +462,10 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
     if (rc) { miosqp_qp_cleanup(e); return rc; }
   }
+  if (e->coop) {
+    int rc = calibrate_coop_nap(e);
+    if (rc) { miosqp_qp_cleanup(e); return rc; }
+  }
   *out = e;
   return 0;
 }
@@ -656,7 +661,8 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[1] = e->fa.nnz_panel;
   out[2] = e->n;
   out[3] = (int64_t)b[4];
-  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0);
+  out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0) |
+           ((e->d.coop_nap & 0xff) << 8);
   return 0;
 }
 
