@@ -429,8 +429,15 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           if (!rc) rc = dalloc(e, &d.coop_reg, 64);
           double *Kc = nullptr;
           if (!rc) rc = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
+          const bool timing = getenv("MIOSQP_SETUP_TIMING") != nullptr;
+          if (timing) HIPCHK(hipStreamSynchronize(e->stream));
+          const double tk0 = wall();
           if (!rc) rc = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
           if (rc) { miosqp_qp_cleanup(e); return rc; }
+          if (timing) {
+            HIPCHK(hipStreamSynchronize(e->stream));
+            fprintf(stderr, "[miosqp setup] %-32s %8.1f ms\n", "explicit KKT inverse (device)", 1e3 * (wall() - tk0));
+          }
           d.W = Wd;
           d.Kc = Kc;
           hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
