@@ -665,3 +665,44 @@ def test_engine_form_boundaries(oracle_mod, n, m, p):
     rg, ro = g.solve(), o.solve()
     assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), N
     assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL
+
+
+def test_randomised_sweep_over_shapes_forms_and_bounds(oracle_mod):
+    """60 small random instances: random shape and density, random engine form, random warm start, bounds
+    randomly tightened (some relaxations become infeasible): status, iteration count and solution equal
+    the oracle's every time."""
+    import scipy.sparse as spa
+    from miosqp_amd import qp
+    rng = np.random.RandomState(2024)
+    seen = set()
+    for trial in range(60):
+        n = int(rng.randint(2, 45))
+        m = int(rng.randint(1, 90))
+        p = int(rng.randint(0, n + 1))
+        dens = float(rng.choice([0.05, 0.2, 0.7, 1.0]))
+        pr = problems.random_miqp(n, m, p, density=dens, seed=1000 + trial)
+        A, l, u = problems.extended(pr)
+        A = spa.csc_matrix(A)
+        M = A.shape[0]
+        form = [dict(fold=0, resident=0, coop=0), dict(fold=1, resident=0, coop=0), dict(fold=1, resident=1, coop=0),
+                dict(coop=1, resident=0), dict()][int(rng.randint(0, 5))]
+        l, u = l.copy(), u.copy()
+        for j in rng.choice(M, size=min(M, 3), replace=False):  # tighten or cross a few intervals' centres
+            c0 = 0.5 * (l[j] + u[j]) if np.isfinite(l[j]) and np.isfinite(u[j]) else 0.0
+            w = float(rng.choice([0.0, 0.05, 1.0]))
+            l[j], u[j] = c0 - w + rng.randn() * 0.5, c0 + w + rng.randn() * 0.5
+            if l[j] > u[j]:
+                l[j], u[j] = u[j], l[j]
+        g, o = qp.OSQP(), oracle_mod.OSQP()
+        g.setup(pr["P"], pr["q"], A, l, u, **form, **problems.QP_SETTINGS)
+        o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+        x0, y0 = rng.randn(n) * rng.choice([0.0, 1.0]), rng.randn(M) * rng.choice([0.0, 1.0])
+        g.warm_start(x=x0, y=y0)
+        o.warm_start(x=x0, y=y0)
+        rg, ro = g.solve(), o.solve()
+        fs = g.factor_stats()
+        seen.add((fs["fold"], fs["resident"], fs["coop"], ro.info.status_val))
+        assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), (trial, n, m, p, dens, form)
+        np.testing.assert_allclose(rg.x, ro.x, rtol=1e-6, atol=1e-7, equal_nan=True, err_msg=str((trial, form)))
+        np.testing.assert_allclose(rg.y, ro.y, rtol=1e-6, atol=1e-7, equal_nan=True, err_msg=str((trial, form)))
+    assert len({s[:3] for s in seen}) >= 4 and len({s[3] for s in seen}) >= 2, seen
