@@ -112,7 +112,7 @@ struct Dev {
   unsigned long long *coop_buf;  // 2 parities x N x {lo32|tag, hi32|tag}
   unsigned long long *coop_chk;  // 2 x coop_half: the test's operands [y ; x] and [proj(dy) ; dx]
   unsigned long long *coop_q;    // (256 + 16) x COOP_QS: per-workgroup, then per-group norms / sums of the test
-  unsigned *coop_reg;            // start-up registration counter (zeroed before every launch)
+  unsigned long long *coop_reg;  // start-up registration counter (grows by the grid size per launch)
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
   int coop_dbg;                  // debug ablation: 1 = no gather
   int coop_nap;                  // 64-clock naps between publishing and the first poll of a round (calibrated)
