@@ -584,10 +584,8 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, 
   memcpy(e->h_in + 2 * (size_t)M + n, y0, sizeof(double) * M);
   HIPCHK(hipEventRecord(e->ev0, e->stream));
   HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * (3 * (size_t)M + n), hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(k_scale_bounds, dim3((M + 255) / 256), dim3(256), 0, e->stream, e->d);
-  enqueue_warm(e);
-  hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, e->d);
-  hipLaunchKernelGGL(k_init_wh, dim3(((M > n ? M : n) + 255) / 256), dim3(256), 0, e->stream, e->d);
+  hipLaunchKernelGGL(k_node_pre, dim3(((M > n ? M : n) + 255) / 256), dim3(256), 0, e->stream, e->d);
+  DISPATCH_TPR(e->tpr_pc, k_warm_zw, M, e->stream, e->d);
   int rc = run_loop(e);
   if (!rc) rc = finish_and_fetch(e, 1, x_out, y_out, info, t0);
   return rc;
