@@ -114,7 +114,7 @@ struct Dev {
   unsigned long long *coop_q;    // (256 + 16) x COOP_QS: per-workgroup, then per-group norms / sums of the test
   unsigned long long *coop_reg;  // start-up registration counter (grows by the grid size per launch)
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
-  int coop_dbg;                  // debug ablation: 1 = no gather
+  int coop_dbg;                  // debug: 1 = no gather (ablation), 64 = workgroup 1 never starts (fault injection)
   int coop_nap;                  // 64-clock naps between publishing and the first poll of a round (calibrated)
   int coop_stride;               // 8-byte words between the blocks of consecutive workgroups (>= 2 RW)
   size_t coop_half;              // words per parity

@@ -706,3 +706,28 @@ def test_randomised_sweep_over_shapes_forms_and_bounds(oracle_mod):
         np.testing.assert_allclose(rg.x, ro.x, rtol=1e-6, atol=1e-7, equal_nan=True, err_msg=str((trial, form)))
         np.testing.assert_allclose(rg.y, ro.y, rtol=1e-6, atol=1e-7, equal_nan=True, err_msg=str((trial, form)))
     assert len({s[:3] for s in seen}) >= 4 and len({s[3] for s in seen}) >= 2, seen
+
+
+def test_cooperative_solver_reports_a_missing_workgroup_and_recovers(oracle_mod, monkeypatch):
+    """Fault injection: one workgroup of the cooperative launch never starts.  The others give up after
+    their bounded wait (about 2 s), the call fails loudly with MIOSQP_EHIP instead of hanging or returning
+    numbers, and an engine set up afterwards works."""
+    import time
+    from miosqp_amd import qp
+    pr = problems.random_miqp(60, 120, 30, seed=11)
+    A, l, u = problems.extended(pr)
+    monkeypatch.setenv("MIOSQP_COOP_NAP", "12")  # calibration would hit the fault first
+    monkeypatch.setenv("MIOSQP_COOP_DBG", "64")
+    bad = qp.OSQP()
+    bad.setup(pr["P"], pr["q"], A, l, u, coop=1, resident=0, **problems.QP_SETTINGS)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="timed out"):
+        bad.solve()
+    assert time.time() - t0 < 30.0
+    monkeypatch.delenv("MIOSQP_COOP_DBG")
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, coop=1, resident=0, **problems.QP_SETTINGS)
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    rg, ro = g.solve(), o.solve()
+    assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
+    assert rel(rg.x, ro.x) <= SOL_TOL
