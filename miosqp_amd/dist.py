@@ -119,8 +119,6 @@ class ShardedSearch(object):
         self.global_upper = np.inf
         import os
         self.rebalance = os.environ.get("MIOSQP_REBALANCE", "1") != "0"
-        # open leaves needed before the replicated phase ends and the leaves are dealt (0 = one per rank)
-        self.deal_at = int(os.environ.get("MIOSQP_DEAL_AT", "0"))
         self.moved = 0
 
     def begin_instance(self):
@@ -195,7 +193,7 @@ class ShardedSearch(object):
         w = self.work
         rule = w.settings['tree_explor_rule']
         if self.replicated:
-            if len(w.leaves) >= (self.deal_at or self.comm.world) or not w.leaves:
+            if len(w.leaves) >= self.comm.world or not w.leaves:
                 if w.leaves:
                     self.deal()
             else:
