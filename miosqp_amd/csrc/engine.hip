@@ -444,6 +444,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         }
       }
       if (const char *ev = getenv("MIOSQP_BD_CFG")) e->bd_cfg = atoi(ev);
+      if (const char *ev = getenv("MIOSQP_SPIN_WAIT")) e->spin_wait = atoi(ev) != 0;
       if (const char *ev = getenv("MIOSQP_COMPACT")) e->compact = atoi(ev) != 0;
       if (const char *ev = getenv("MIOSQP_BM_ABLATE")) d.bm_ablate = atoi(ev);
       if (const char *ev = getenv("MIOSQP_FOLD_TPR")) {  // tuning hook: "fwd,x,c"
