@@ -412,18 +412,8 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           rc = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
           if (!rc) rc = dalloc(e, &d.coop_tag, 64);
           d.coop_stride = 2 * rw;
-          if (const char *ev = getenv("MIOSQP_COOP_STRIDE")) d.coop_stride = std::max(2 * rw, atoi(ev) / 8);
           d.coop_half = (size_t)T * d.coop_stride;
-          int memkind = 0;
-          if (const char *ev = getenv("MIOSQP_COOP_MEM")) memkind = atoi(ev);
-          if (!rc && memkind) {
-            void *pb = nullptr;
-            const size_t bytes = (2 * d.coop_half + 64) * 8;
-            HIPCHK(hipExtMallocWithFlags(&pb, bytes, memkind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
-            HIPCHK(hipMemset(pb, 0, bytes));
-            e->allocs.push_back(pb);
-            d.coop_buf = (unsigned long long *)pb;
-          } else if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
+          if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_chk, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_q, (size_t)(256 + 16) * COOP_QS + 64);
           if (!rc) rc = dalloc(e, &d.coop_reg, 64);
