@@ -132,6 +132,9 @@ def main():
     one_dev = os.environ.get("MIOSQP_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local_rank = 0
+        # several processes time-sharing one GPU cannot keep a cooperative launch co-resident (it needs the
+        # device to itself, one process per GPU as deployed): this test mode uses the two-kernel form
+        os.environ.setdefault("MIOSQP_COOP", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -192,6 +195,7 @@ def main():
     n0, i0, inst0 = srch.nodes, srch.iters, stream["instances"]
     t0 = time.perf_counter()
     run_steps(args.steps, args.wave, False)
+    srch.drain()  # the exchange still in flight belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
     loop_ms, loop_iters = eng.loop_stats()
@@ -217,6 +221,7 @@ def main():
         n1, i1 = srch.nodes, srch.iters
         t1 = time.perf_counter()
         run_steps(args.batch_waves, args.batch_width, True)
+        srch.drain()
         sync()
         dtb = time.perf_counter() - t1
         bms, bit, bnode = eng.batch_stats()

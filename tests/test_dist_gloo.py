@@ -26,10 +26,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n,m,p,seed,per_rank", [(20, 100, 10, 3, 1), (30, 150, 15, 4, 3)])
-def test_two_ranks_find_the_same_optimum(tmp_path, oracle_mod, n, m, p, seed, per_rank):
+@pytest.mark.parametrize("n,m,p,seed,per_rank,lag", [(20, 100, 10, 3, 1, 1), (30, 150, 15, 4, 3, 1), (30, 150, 15, 4, 1, 0)])
+def test_two_ranks_find_the_same_optimum(tmp_path, oracle_mod, n, m, p, seed, per_rank, lag):
     out = str(tmp_path / "res.json")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MIOSQP_EXCHANGE_LAG=str(lag))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(m), str(p), str(seed), str(per_rank)]

@@ -36,8 +36,11 @@ def _run(world, pr, per_rank, batched):
     return out
 
 
+@pytest.mark.parametrize("lag", [0, 1])
 @pytest.mark.parametrize("world,per_rank,batched", [(4, 1, False), (8, 2, False), (4, 4, True)])
-def test_many_ranks_agree_with_the_sequential_search(world, per_rank, batched):
+def test_many_ranks_agree_with_the_sequential_search(world, per_rank, batched, lag, monkeypatch):
+    """lag 0: blocking exchange after every step; lag 1: the exchange of a step is applied one step later."""
+    monkeypatch.setenv("MIOSQP_EXCHANGE_LAG", str(lag))
     pr = problems.random_miqp(30, 150, 15, seed=4)
     ref = bnb.MIOSQP(backend=digest_backend)
     ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],

@@ -11,12 +11,15 @@ class ThreadWorld(object):
         self.world = world
         self.bar = threading.Barrier(world, timeout=300)
         self.slots = [None] * world
+        self.rounds = {}  # exchange number -> per-rank deposits of post()
+        self.cv = threading.Condition()
 
 
 class ThreadComm(object):
     def __init__(self, tw, rank):
         self.tw, self.rank, self.world = tw, rank, tw.world
         self._counts = None
+        self._posted = 0
 
     def _all(self, obj):
         tw = self.tw
@@ -26,8 +29,28 @@ class ThreadComm(object):
         tw.bar.wait()
         return out
 
+    def post(self, value, x, nleaves):
+        """Non-blocking half: deposit this rank's entry of exchange number k."""
+        tw = self.tw
+        k = self._posted
+        self._posted += 1
+        with tw.cv:
+            tw.rounds.setdefault(k, [None] * self.world)[self.rank] = (value, nleaves, None if x is None else np.array(x))
+            tw.cv.notify_all()
+        return k
+
+    def complete(self, k, have=None):
+        tw = self.tw
+        with tw.cv:
+            ok = tw.cv.wait_for(lambda: all(e is not None for e in tw.rounds.get(k, [None])), timeout=300)
+            assert ok, "exchange %d never completed" % k
+            tab = list(tw.rounds[k])
+        return self._decide(tab, have)
+
     def exchange(self, value, x, nleaves, have=None):
-        tab = self._all((value, nleaves, None if x is None else np.array(x)))
+        return self.complete(self.post(value, x, nleaves), have)
+
+    def _decide(self, tab, have):
         self._counts = [int(t[1]) for t in tab]
         vals = np.array([t[0] for t in tab])
         owner = int(np.argmin(vals))

@@ -16,6 +16,7 @@ import digest_backend
 from miosqp_amd import bnb, dist, problems
 
 import os
+os.environ.setdefault("MIOSQP_EXCHANGE_LAG", "0")  # the model clock has its own notion of lag (SIM_LAG)
 T_ITER, T_NODE, T_SYNC = 2.83e-6, 170e-6, 60e-6
 LAG = int(os.environ.get("SIM_LAG", "0"))  # model of a non-blocking exchange: wait only for the one LAG steps back
 
@@ -64,6 +65,12 @@ class SimComm(object):
         if not np.isfinite(best) or not best < prev:
             return best, owner, None, total
         return best, owner, np.array(tab[owner][2]), total
+
+    def post(self, value, x, nleaves):
+        return (value, None if x is None else np.array(x), nleaves)
+
+    def complete(self, h, have=None):
+        return self.exchange(h[0], h[1], h[2], have)
 
     def leaf_counts(self):
         return list(self._counts)
