@@ -573,13 +573,24 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, 
   memcpy(e->h_in + M, u, sizeof(double) * M);
   memcpy(e->h_in + 2 * (size_t)M, x0, sizeof(double) * n);
   memcpy(e->h_in + 2 * (size_t)M + n, y0, sizeof(double) * M);
-  HIPCHK(hipEventRecord(e->ev0, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * (3 * (size_t)M + n), hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(k_node_pre, dim3(((M > n ? M : n) + 255) / 256), dim3(256), 0, e->stream, e->d);
-  DISPATCH_TPR(e->tpr_pc, k_warm_zw, M, e->stream, e->d);
-  int rc = run_loop(e);
-  if (!rc) rc = finish_and_fetch(e, 1, x_out, y_out, info, t0);
-  return rc;
+  for (int attempt = 0;; attempt++) {
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * (3 * (size_t)M + n), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_node_pre, dim3(((M > n ? M : n) + 255) / 256), dim3(256), 0, e->stream, e->d);
+    DISPATCH_TPR(e->tpr_pc, k_warm_zw, M, e->stream, e->d);
+    int rc = run_loop(e);
+    if (!rc) rc = finish_and_fetch(e, 1, x_out, y_out, info, t0);
+    if (rc != MIOSQP_EHIP || !e->coop || !e->coop_timed_out || attempt > 0) return rc;
+    // The cooperative launch could not keep its workgroups co-resident (something else is using the
+    // device).  The node's inputs are still staged, so the node is redone -- and this engine continues --
+    // in the two-kernel product form, which has no such requirement.  Not silent: one line on stderr.
+    fprintf(stderr, "miosqp: %s; this engine continues with the two-kernel form\n", g_err.c_str());
+    e->coop = false;
+    e->coop_timed_out = false;
+    rc = capture_chunk(e, e->chunk, &e->g_full, &e->x_full);
+    if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
+    if (rc) return rc;
+  }
 }
 
 int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const double *u, const double *x0,

@@ -710,8 +710,9 @@ def test_randomised_sweep_over_shapes_forms_and_bounds(oracle_mod):
 
 def test_cooperative_solver_reports_a_missing_workgroup_and_recovers(oracle_mod, monkeypatch):
     """Fault injection: one workgroup of the cooperative launch never starts.  The others give up after
-    their bounded wait (about 2 s), the call fails loudly with MIOSQP_EHIP instead of hanging or returning
-    numbers, and an engine set up afterwards works."""
+    their bounded wait (about 2 s); `solve` fails loudly with MIOSQP_EHIP instead of hanging or returning
+    numbers; `solve_node` (whose inputs are still staged) redoes the node in the two-kernel form with a
+    line on stderr and the engine stays in that form; an engine set up afterwards works."""
     import time
     from miosqp_amd import qp
     pr = problems.random_miqp(60, 120, 30, seed=11)
@@ -724,7 +725,20 @@ def test_cooperative_solver_reports_a_missing_workgroup_and_recovers(oracle_mod,
     with pytest.raises(RuntimeError, match="timed out"):
         bad.solve()
     assert time.time() - t0 < 30.0
+    # a node relaxation still has its inputs staged: it is redone in the two-kernel form, and the engine stays there
+    bad.set_integer_rows(pr["i_idx"], pr["A"].shape[0])
+    ref = qp.OSQP()
     monkeypatch.delenv("MIOSQP_COOP_DBG")
+    ref.setup(pr["P"], pr["q"], A, l, u, coop=0, resident=0, **problems.QP_SETTINGS)
+    ref.set_integer_rows(pr["i_idx"], pr["A"].shape[0])
+    x0, y0 = np.zeros(60), np.zeros(A.shape[0])
+    ra, rb = bad.solve_node(l, u, x0, y0), ref.solve_node(l, u, x0, y0)
+    assert bad.factor_stats()["coop"] is False
+    assert (ra.status_val, ra.iter) == (rb.status_val, rb.iter)
+    np.testing.assert_array_equal(ra.x, rb.x)
+    ra2 = bad.solve_node(l, u, ra.x, ra.y)
+    rb2 = ref.solve_node(l, u, rb.x, rb.y)
+    assert (ra2.status_val, ra2.iter) == (rb2.status_val, rb2.iter)
     g, o = qp.OSQP(), oracle_mod.OSQP()
     g.setup(pr["P"], pr["q"], A, l, u, coop=1, resident=0, **problems.QP_SETTINGS)
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
