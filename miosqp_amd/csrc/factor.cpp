@@ -54,16 +54,50 @@ void parallel_chunks(int64_t count, int64_t work_per_item, const std::function<v
   for (auto &th : pool) th.join();
 }
 
+// contiguous column ranges [lo, hi) for the parallel loops of the equilibration (max and element-wise
+// products only: the results do not depend on the split)
+constexpr int kColChunks = 32;
+inline void col_range(int n, int64_t c, int &lo, int &hi) {
+  lo = (int)((int64_t)n * c / kColChunks);
+  hi = (int)((int64_t)n * (c + 1) / kColChunks);
+}
+
 // column inf-norms of a symmetric matrix given by its upper triangle
 void sym_col_norms(int n, const std::vector<int> &Pp, const std::vector<int> &Pi,
                    const std::vector<double> &Px, std::vector<double> &out) {
-  std::fill(out.begin(), out.end(), 0.0);
-  for (int j = 0; j < n; j++)
-    for (int p = Pp[j]; p < Pp[j + 1]; p++) {
-      double a = std::fabs(Px[p]);
-      out[j] = std::max(out[j], a);
-      out[Pi[p]] = std::max(out[Pi[p]], a);
+  const int64_t nnz = Pp[n];
+  if (nnz < ((int64_t)1 << 20)) {
+    std::fill(out.begin(), out.end(), 0.0);
+    for (int j = 0; j < n; j++)
+      for (int p = Pp[j]; p < Pp[j + 1]; p++) {
+        double a = std::fabs(Px[p]);
+        out[j] = std::max(out[j], a);
+        out[Pi[p]] = std::max(out[Pi[p]], a);
+      }
+    return;
+  }
+  // every chunk of columns fills its own array (an entry touches its column and its row), then a max-merge
+  std::vector<double> part((size_t)kColChunks * n, 0.0);
+  parallel_chunks(kColChunks, nnz / kColChunks + 1, [&](int64_t c) {
+    int lo, hi;
+    col_range(n, c, lo, hi);
+    double *o = part.data() + (size_t)c * n;
+    for (int j = lo; j < hi; j++)
+      for (int p = Pp[j]; p < Pp[j + 1]; p++) {
+        double a = std::fabs(Px[p]);
+        o[j] = std::max(o[j], a);
+        o[Pi[p]] = std::max(o[Pi[p]], a);
+      }
+  });
+  parallel_chunks(kColChunks, (int64_t)n, [&](int64_t c) {
+    int lo, hi;
+    col_range(n, c, lo, hi);
+    for (int j = lo; j < hi; j++) {
+      double m = 0.0;
+      for (int k = 0; k < kColChunks; k++) m = std::max(m, part[(size_t)k * n + j]);
+      out[j] = m;
     }
+  });
 }
 
 // rows -> padded compressed rows
@@ -143,8 +177,12 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
       }
     for (int j = 0; j < n; j++) dt[j] = 1.0 / std::sqrt(clamp_scaling(dt[j]));
     for (int i = 0; i < M; i++) et[i] = 1.0 / std::sqrt(clamp_scaling(et[i]));
-    for (int j = 0; j < n; j++)
-      for (int p = s.Pp[j]; p < s.Pp[j + 1]; p++) s.Px[p] *= dt[j] * dt[s.Pi[p]];
+    parallel_chunks(kColChunks, (int64_t)s.Pp[n] / kColChunks + 1, [&](int64_t c) {
+      int lo, hi;
+      col_range(n, c, lo, hi);
+      for (int j = lo; j < hi; j++)
+        for (int p = s.Pp[j]; p < s.Pp[j + 1]; p++) s.Px[p] *= dt[j] * dt[s.Pi[p]];
+    });
     for (int j = 0; j < n; j++)
       for (int p = s.Ap[j]; p < s.Ap[j + 1]; p++) s.Ax[p] *= dt[j] * et[s.Ai[p]];
     for (int j = 0; j < n; j++) {
@@ -160,7 +198,11 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
     double nq = 0;
     for (int j = 0; j < n; j++) nq = std::max(nq, std::fabs(s.q[j]));
     double ct = 1.0 / clamp_scaling(std::max(mean, clamp_scaling(nq)));
-    for (double &v : s.Px) v *= ct;
+    parallel_chunks(kColChunks, (int64_t)s.Pp[n] / kColChunks + 1, [&](int64_t c) {
+      int lo, hi;
+      col_range(n, c, lo, hi);
+      for (int p = s.Pp[lo]; p < s.Pp[hi]; p++) s.Px[p] *= ct;
+    });
     for (double &v : s.q) v *= ct;
     s.c *= ct;
   }

@@ -155,3 +155,29 @@ def test_nonconvex_rejected(hh):
     h = hh.hh_build(8, A.shape[0], _i(k[0]), _i(k[1]), _d(k[2]), _i(k[3]), _i(k[4]), _d(k[5]), _d(k[6]),
                     0, 0.1, 1e-6)
     assert not h
+
+
+def test_equilibration_of_a_large_matrix_takes_the_threaded_path(hh, oracle_mod):
+    """Above 2^20 stored entries of P the column norms and the element-wise products of the Ruiz passes run on
+    several host threads (max-merges and independent products: the result cannot depend on the split)."""
+    import scipy.sparse as spa
+    rng = np.random.RandomState(7)
+    n, m = 1500, 40
+    B = rng.randn(n, n)
+    P = spa.csc_matrix(B @ B.T / n + np.eye(n))
+    assert spa.triu(P).nnz > (1 << 20)
+    A = spa.random(m, n, density=0.3, random_state=rng, format="csc")
+    pr = dict(P=P, q=rng.randn(n), A=A, l=-np.ones(m), u=np.ones(m), i_idx=np.arange(0), i_l=np.zeros(0), i_u=np.zeros(0))
+    h, P2, A2, n2, M = _build(hh, pr)
+    try:
+        D, E, qs, c = np.empty(n), np.empty(M), np.empty(n), C.c_double()
+        hh.hh_scaling(h, _d(D), _d(E), C.byref(c), _d(qs))
+        s = oracle_mod.OSQP()
+        _, l, u = problems.extended(pr)
+        s.setup(P, pr["q"], A2, l, u)
+        Do, Eo, co = s.scaling()
+        np.testing.assert_allclose(D, Do, rtol=1e-14)
+        np.testing.assert_allclose(E, Eo, rtol=1e-14)
+        assert abs(c.value - co) <= 1e-14 * co
+    finally:
+        hh.hh_free(h)
