@@ -146,6 +146,8 @@ class ShardedSearch(object):
         # the next node, which could only be exercised over gloo here.
         self.lag = int(os.environ.get("MIOSQP_EXCHANGE_LAG", "0")) if self.comm.world > 1 else 0
         self._pending = None
+        self._inflight = None  # (future, leaves) of the wave being solved on the worker thread
+        self._pool = None
         if hasattr(self.comm, "n_hint"):
             self.comm.n_hint = self.work.data.n
         self.moved = 0
@@ -153,6 +155,7 @@ class ShardedSearch(object):
     def begin_instance(self):
         """Call after MIOSQP.update_vectors (new root on every rank).  An exchange still in flight belongs
         to the closed tree: it is completed (every rank takes part) and ignored."""
+        self.flush_wave()
         self.drain(apply=False)
         self.replicated = True
         self.global_upper = np.inf
@@ -178,9 +181,8 @@ class ShardedSearch(object):
         self._count(leaf)
         return leaf
 
-    def _visit_wave(self, rule, width):
-        """Up to `width` local leaves in ONE batched relaxation call, taken in the order the
-        exploration rule would visit them, then bound/branch each in that order."""
+    def _select_wave(self, rule, width):
+        """Takes (removes) up to `width` local leaves in the order the exploration rule would visit them."""
         w = self.work
         wave = []
         if w.leaves:
@@ -196,17 +198,53 @@ class ShardedSearch(object):
             wave = [w.leaves[i] for i in order]
             taken = set(int(i) for i in order)
             w.leaves = [lf for i, lf in enumerate(w.leaves) if i not in taken]
-        if wave:
-            w.solve_wave(wave)
-            w.defer_lower = True  # one pass over the leaves per wave instead of one per node
-            for leaf in wave:
-                w.bound_and_branch(leaf)
-                w.iter_num += 1
-                self._count(leaf)
-            w.defer_lower = False
-            if w.leaves:
-                w.lower_glob = min(lf.lower for lf in w.leaves)
+        return wave
+
+    def _process_wave(self, wave):
+        """Bound and branch the solved leaves of a wave, in the wave's order."""
+        w = self.work
+        w.defer_lower = True  # one pass over the leaves per wave instead of one per node
+        for leaf in wave:
+            w.bound_and_branch(leaf)
+            w.iter_num += 1
+            self._count(leaf)
+        w.defer_lower = False
+        if w.leaves:
+            w.lower_glob = min(lf.lower for lf in w.leaves)
+
+    def _visit_wave(self, rule, width, pipelined=False):
+        """Up to `width` local leaves in ONE batched relaxation call, taken in the order the
+        exploration rule would visit them, then bound/branch each in that order.
+        `pipelined`: the call runs on a worker thread (the engine releases the GIL) while this thread bounds
+        and branches the PREVIOUS wave; a wave is then chosen before the previous one's children exist and
+        before its incumbents can prune (the search stays exact, it may visit more nodes)."""
+        w = self.work
+        wave = self._select_wave(rule, width)
+        if not pipelined:
+            self.flush_wave()
+            if wave:
+                w.solve_wave(wave)
+                self._process_wave(wave)
+            return len(wave)
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1)
+        prev, self._inflight = self._inflight, ((self._pool.submit(w.solve_wave, wave), wave) if wave else None)
+        if prev is not None:
+            prev[0].result()
+            self._process_wave(prev[1])
         return len(wave)
+
+    def flush_wave(self):
+        """Waits for the wave in flight (pipelined mode) and bounds/branches it."""
+        if self._inflight is not None:
+            (fut, wave), self._inflight = self._inflight, None
+            fut.result()
+            self._process_wave(wave)
+
+    def _open(self):
+        """Open leaves of this rank, the ones being solved right now included."""
+        return len(self.work.leaves) + (len(self._inflight[1]) if self._inflight is not None else 0)
 
     def expand_until(self, n_leaves, max_nodes=10 ** 9):
         """Node-at-a-time exploration (identical on every rank while replicated) until
@@ -219,10 +257,12 @@ class ShardedSearch(object):
             done += 1
         return done
 
-    def step(self, nodes_per_rank=1, batched=False):
+    def step(self, nodes_per_rank=1, batched=False, pipelined=False):
         """One wave.  Returns the number of leaves open over all ranks afterwards."""
         w = self.work
         rule = w.settings['tree_explor_rule']
+        if not (batched and pipelined):
+            self.flush_wave()  # the engine is used from this thread below
         if self.replicated:
             if len(w.leaves) >= self.comm.world or not w.leaves:
                 if w.leaves:
@@ -231,7 +271,7 @@ class ShardedSearch(object):
                 self._visit(rule)  # same node on every rank; nothing to exchange
                 return max(1, len(w.leaves)) if w.leaves else 0
         if batched:
-            self._visit_wave(rule, nodes_per_rank)
+            self._visit_wave(rule, nodes_per_rank, pipelined)
         else:
             for _ in range(nodes_per_rank):
                 if not w.leaves:
@@ -249,8 +289,8 @@ class ShardedSearch(object):
         known yet)."""
         w = self.work
         if self.comm.world == 1:
-            return len(w.leaves)
-        h = self.comm.post(w.upper_glob, w.x, len(w.leaves))
+            return self._open()
+        h = self.comm.post(w.upper_glob, w.x, self._open())
         if self.lag == 0:
             return self._apply(h)
         prev, self._pending = self._pending, h
@@ -319,13 +359,14 @@ class ShardedSearch(object):
     def open_leaves(self):
         return int(self.comm.sum([len(self.work.leaves)])[0])
 
-    def run(self, nodes_per_rank=1, max_waves=10 ** 9, batched=False):
+    def run(self, nodes_per_rank=1, max_waves=10 ** 9, batched=False, pipelined=False):
         """Waves until no rank has leaves left (or max_waves)."""
         waves = 0
         total = 1
         while waves < max_waves and total > 0:
-            total = self.step(nodes_per_rank, batched)
+            total = self.step(nodes_per_rank, batched, pipelined)
             waves += 1
+        self.flush_wave()
         self.drain()
         w = self.work
         w.get_return_status()

@@ -22,8 +22,8 @@ def test_traces_through_fused_node_and_digest(name):
         np.testing.assert_allclose(g["trace"], e["trace"], rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("width", [1, 3, 16])
-def test_wave_search_reaches_the_same_optimum(width):
+@pytest.mark.parametrize("width,pipelined", [(1, False), (3, False), (16, False), (4, True), (16, True)])
+def test_wave_search_reaches_the_same_optimum(width, pipelined):
     pr = problems.random_miqp(20, 100, 10, seed=3)
     ref = bnb.MIOSQP(backend=digest_backend)
     ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
@@ -33,9 +33,10 @@ def test_wave_search_reaches_the_same_optimum(width):
     m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
             dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
     s = dist.ShardedSearch(m)
-    s.run(nodes_per_rank=width, batched=True)
+    s.run(nodes_per_rank=width, batched=True, pipelined=pipelined)
     assert m.work.status == r.status == bnb.MI_SOLVED
     assert abs(m.work.upper_glob - r.upper_glob) <= 1e-3 * max(1.0, abs(r.upper_glob))
     np.testing.assert_array_equal(m.work.x[pr["i_idx"]], r.x[pr["i_idx"]])
+    assert s._inflight is None and not m.work.leaves
     if width == 1:  # a wave of one is the sequential search
         assert s.nodes == ref.work.iter_num - 1 and s.iters == ref.work.osqp_iter

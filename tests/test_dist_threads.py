@@ -22,7 +22,7 @@ def _run(world, pr, per_rank, batched):
             m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
                     dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
             s = dist.ShardedSearch(m, ThreadComm(tw, rank))
-            s.run(nodes_per_rank=per_rank, batched=batched)
+            s.run(nodes_per_rank=per_rank, batched=bool(batched), pipelined=batched == "pipelined")
             out[rank] = dict(upper=m.work.upper_glob, x=np.array(m.work.x), nodes=s.nodes, moved=s.moved,
                              status=m.work.status, leaves=len(m.work.leaves))
         except Exception as e:  # a dead rank would leave the others at a barrier
@@ -37,7 +37,7 @@ def _run(world, pr, per_rank, batched):
 
 
 @pytest.mark.parametrize("lag", [0, 1])
-@pytest.mark.parametrize("world,per_rank,batched", [(4, 1, False), (8, 2, False), (4, 4, True)])
+@pytest.mark.parametrize("world,per_rank,batched", [(4, 1, False), (8, 2, False), (4, 4, True), (4, 4, "pipelined")])
 def test_many_ranks_agree_with_the_sequential_search(world, per_rank, batched, lag, monkeypatch):
     """lag 0: blocking exchange after every step; lag 1: the exchange of a step is applied one step later."""
     monkeypatch.setenv("MIOSQP_EXCHANGE_LAG", str(lag))
