@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--wave", type=int, default=1, help="node relaxations per rank per step")
+    ap.add_argument("--step-budget-ms", type=float, default=2.0,
+                    help="with more than one rank a step is 'node relaxations for this long, at least one' "
+                         "instead of a fixed count (ranks then meet at the exchange without waiting for the "
+                         "rank that drew the expensive node); 0 = fixed count (--wave)")
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg5"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -184,9 +188,11 @@ def main():
         comm.barrier()
         torch.cuda.synchronize()
 
+    budget = 1e-3 * args.step_budget_ms if (world > 1 and args.step_budget_ms > 0) else None
+
     def run_steps(count, width, batched):
         for _ in range(count):
-            if srch.step(width, batched) == 0:
+            if srch.step(width, batched, budget=None if batched else budget) == 0:
                 next_instance()
 
     run_steps(args.warmup, args.wave, False)
@@ -272,8 +278,10 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                    nodes_per_s=round(nodes / dt_max, 2), iters_per_node=round(iters / max(1.0, nodes), 1),
                    config=dict(workload="BASELINE configs[1]: random_miqp n=%d m=%d p=%d density %.2f seed %d, "
-                                        "%d node(s) per rank per step, leaves sharded over %d GPU(s)" %
-                                        (cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed, args.wave, world),
+                                        "%s per rank per step, leaves sharded over %d GPU(s)" %
+                                        (cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed,
+                                         ("node relaxations for %.1f ms" % args.step_budget_ms) if budget
+                                         else "%d node(s)" % args.wave, world),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
                                factor_form="explicit KKT inverse in registers, cooperative launch per node"
                                if fs["coop"] else "product form L^-1 (2 launches/iteration)" if fs["fold"]

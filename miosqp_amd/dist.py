@@ -146,6 +146,8 @@ class ShardedSearch(object):
         # the next node, which could only be exercised over gloo here.
         self.lag = int(os.environ.get("MIOSQP_EXCHANGE_LAG", "0")) if self.comm.world > 1 else 0
         self._pending = None
+        import time
+        self.clock = time.perf_counter  # what `budget` is measured with (the simulator substitutes its model clock)
         self._inflight = None  # (future, leaves) of the wave being solved on the worker thread
         self._pool = None
         if hasattr(self.comm, "n_hint"):
@@ -257,8 +259,11 @@ class ShardedSearch(object):
             done += 1
         return done
 
-    def step(self, nodes_per_rank=1, batched=False, pipelined=False):
-        """One wave.  Returns the number of leaves open over all ranks afterwards."""
+    def step(self, nodes_per_rank=1, batched=False, pipelined=False, budget=None):
+        """One wave.  Returns the number of leaves open over all ranks afterwards.
+        `budget` (seconds, node-at-a-time mode): instead of a fixed count, keep visiting local leaves until
+        that much time has passed (at least one node) -- ranks then reach the exchange at about the same
+        moment whatever their nodes cost, which removes most of the lock-step loss."""
         w = self.work
         rule = w.settings['tree_explor_rule']
         if not (batched and pipelined):
@@ -272,6 +277,12 @@ class ShardedSearch(object):
                 return max(1, len(w.leaves)) if w.leaves else 0
         if batched:
             self._visit_wave(rule, nodes_per_rank, pipelined)
+        elif budget:
+            t0 = self.clock()
+            while w.leaves:
+                self._visit(rule)
+                if self.clock() - t0 >= budget:
+                    break
         else:
             for _ in range(nodes_per_rank):
                 if not w.leaves:

@@ -55,3 +55,40 @@ def test_many_ranks_agree_with_the_sequential_search(world, per_rank, batched, l
         assert abs(o["upper"] - r.upper_glob) <= 1e-3 * max(1.0, abs(r.upper_glob))
         np.testing.assert_array_equal(o["x"][ii], r.x[ii])
     assert sum(o["nodes"] for o in out) >= 1
+
+
+@pytest.mark.parametrize("budget", [1e-9, 0.05])
+def test_time_budgeted_steps_reach_the_same_optimum(budget):
+    """step(budget=...): node relaxations until the budget is spent (at least one) instead of a fixed count."""
+    pr = problems.random_miqp(30, 150, 15, seed=4)
+    ref = bnb.MIOSQP(backend=digest_backend)
+    ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+              dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    r = ref.solve()
+    world = 4
+    tw = ThreadWorld(world)
+    out, err = [None] * world, []
+
+    def main(rank):
+        try:
+            m = bnb.MIOSQP(backend=digest_backend)
+            m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                    dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+            s = dist.ShardedSearch(m, ThreadComm(tw, rank))
+            while s.step(budget=budget) != 0:
+                pass
+            s.drain()
+            out[rank] = (m.work.upper_glob, np.array(m.work.x), len(m.work.leaves))
+        except Exception as e:
+            err.append(e)
+            tw.bar.abort()
+
+    th = [threading.Thread(target=main, args=(k,)) for k in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not err, err
+    for up, x, nl in out:
+        assert nl == 0 and up == out[0][0]
+        assert abs(up - r.upper_glob) <= 1e-3 * max(1.0, abs(r.upper_glob))
+        # the same integer assignment, to the integrality tolerance (which node delivers the incumbent differs)
+        np.testing.assert_allclose(x[pr["i_idx"]], r.x[pr["i_idx"]], atol=1e-3, rtol=0)

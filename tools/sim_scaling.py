@@ -103,10 +103,12 @@ def rank_main(sw, rank, prob, wave, instances, seed, out):
         sw.busy[rank] += dt
         return leaf
     s._visit = visit
+    s.clock = lambda: sw.clock[rank]
+    budget = float(os.environ.get("SIM_BUDGET", "0")) or None
     rng = np.random.RandomState(seed + 12345)
     cfgm = prob["A"].shape[0]
     for inst in range(instances):
-        while s.step(wave, False) != 0:
+        while s.step(wave, False, budget=budget) != 0:
             pass
         q = rng.randn(prob["A"].shape[1]); u = 2 + rng.rand(cfgm); l = -2 + rng.rand(cfgm)
         m.update_vectors(q=q, l=l, u=u)
