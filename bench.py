@@ -108,10 +108,10 @@ def main():
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--wave", type=int, default=1, help="node relaxations per rank per step")
-    ap.add_argument("--step-budget-ms", type=float, default=2.0,
+    ap.add_argument("--step-budget-ms", type=float, default=-1.0,
                     help="with more than one rank a step is 'node relaxations for this long, at least one' "
                          "instead of a fixed count (ranks then meet at the exchange without waiting for the "
-                         "rank that drew the expensive node); 0 = fixed count (--wave)")
+                         "rank that drew the expensive node); -1 = 0.5 + 0.5 log2(ranks) ms, 0 = fixed count (--wave)")
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg5"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -188,6 +188,9 @@ def main():
         comm.barrier()
         torch.cuda.synchronize()
 
+    if args.step_budget_ms < 0:
+        import math
+        args.step_budget_ms = 0.5 + 0.5 * math.log2(max(1, world))
     budget = 1e-3 * args.step_budget_ms if (world > 1 and args.step_budget_ms > 0) else None
 
     def run_steps(count, width, batched):
