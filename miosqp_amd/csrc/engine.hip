@@ -61,6 +61,13 @@ void set_err(const char *what, hipError_t e, const char *file, int line) {
     }                                                 \
   } while (0)
 
+// The HIP current device is per host thread: every entry point makes the engine's device current
+// first, so a handle can be driven from any thread (e.g. the worker thread of a pipelined wave).
+#define ENTER(e)                                       \
+  do {                                                 \
+    if ((e)->device >= 0) HIPCHK(hipSetDevice((e)->device)); \
+  } while (0)
+
 struct Ctrl {
   int done, status, iter, pad;
   int B, ndone, pad3[2];  // batched mode: active columns, columns already decided
@@ -191,6 +198,7 @@ int miosqp_qp_constant(const char *name) {
 
 int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (!e) return 0;
+  if (e->device >= 0) (void)hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->x_full) hipGraphExecDestroy(e->x_full);
   if (e->x_tail) hipGraphExecDestroy(e->x_tail);
@@ -250,6 +258,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   }
   if (s->device >= 0) HIPCHK(hipSetDevice(s->device));
   miosqp_qp_engine *e = new miosqp_qp_engine();
+  HIPCHK(hipGetDevice(&e->device));
   e->n = n;
   e->M = M;
   e->st = *s;
@@ -473,6 +482,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
 
 int miosqp_qp_update_bounds(miosqp_qp_engine *e, const double *l, const double *u) {
   if (!e || !l || !u) return MIOSQP_EARG;
+  ENTER(e);
   for (int i = 0; i < e->M; i++)
     if (l[i] > u[i]) return MIOSQP_EBOUNDS;
   memcpy(e->h_in, l, sizeof(double) * e->M);
@@ -485,6 +495,7 @@ int miosqp_qp_update_bounds(miosqp_qp_engine *e, const double *l, const double *
 
 int miosqp_qp_update_lin_cost(miosqp_qp_engine *e, const double *q) {
   if (!e || !q) return MIOSQP_EARG;
+  ENTER(e);
   double *hx = e->h_in + 2 * (size_t)e->M;
   memcpy(hx, q, sizeof(double) * e->n);
   HIPCHK(hipMemcpyAsync(e->d.raw_x, hx, sizeof(double) * e->n, hipMemcpyHostToDevice, e->stream));
@@ -502,6 +513,7 @@ static int enqueue_warm(miosqp_qp_engine *e) {
 
 int miosqp_qp_warm_start(miosqp_qp_engine *e, const double *x, const double *y) {
   if (!e || !x || !y) return MIOSQP_EARG;
+  ENTER(e);
   double *hx = e->h_in + 2 * (size_t)e->M;
   memcpy(hx, x, sizeof(double) * e->n);
   memcpy(hx + e->n, y, sizeof(double) * e->M);
@@ -522,6 +534,7 @@ static int begin_solve(miosqp_qp_engine *e) {
 
 int miosqp_qp_solve(miosqp_qp_engine *e, double *x_out, double *y_out, miosqp_qp_info *info) {
   if (!e || !x_out || !y_out || !info) return MIOSQP_EARG;
+  ENTER(e);
   const double t0 = wall();
   int rc = begin_solve(e);
   if (!rc) rc = run_loop(e);
@@ -534,6 +547,7 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
     g_err = "set_integer_rows: need m_orig + n_int == M";
     return MIOSQP_EARG;
   }
+  ENTER(e);
   for (int k = 0; k < n_int; k++)
     if (i_idx[k] < 0 || i_idx[k] >= e->n) return MIOSQP_EARG;
   if (n_int) HIPCHK(hipMemcpy((void *)e->d.i_idx, i_idx, sizeof(int) * n_int, hipMemcpyHostToDevice));
@@ -550,6 +564,7 @@ int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *
     g_err = "set_root: call miosqp_qp_set_integer_rows first";
     return MIOSQP_EARG;
   }
+  ENTER(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   if (e->M > 0) {
     HIPCHK(hipMemcpy(e->d.root_l, l_root, sizeof(double) * e->M, hipMemcpyHostToDevice));
@@ -564,6 +579,7 @@ int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *
 int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, const double *x0,
                          const double *y0, double *x_out, double *y_out, miosqp_qp_info *info) {
   if (!e || !l || !u || !x0 || !y0 || !x_out || !y_out || !info) return MIOSQP_EARG;
+  ENTER(e);
   if (!e->have_int) {
     g_err = "solve_node: call miosqp_qp_set_integer_rows first";
     return MIOSQP_EARG;
@@ -599,6 +615,7 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, 
 int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const double *u, const double *x0,
                           const double *y0, double *x_out, double *y_out, miosqp_qp_info *info) {
   if (!e || B < 0 || (B > 0 && (!l || !u || !x0 || !y0 || !x_out || !y_out || !info))) return MIOSQP_EARG;
+  ENTER(e);
   if (!e->have_int) {
     g_err = "solve_batch: call miosqp_qp_set_integer_rows first";
     return MIOSQP_EARG;
@@ -623,6 +640,7 @@ int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const
 
 int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z, double *y) {
   if (!e || k < 0) return MIOSQP_EARG;
+  ENTER(e);
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, e->d);
   hipLaunchKernelGGL(k_init_wh, dim3(((e->M > e->n ? e->M : e->n) + 255) / 256), dim3(256), 0, e->stream, e->d);
   if (e->resident) {
@@ -691,9 +709,10 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
                              int32_t *nblocks) {
   if (!e || !out || !e->fold || which < 0 || which > 2 || (which == 2 && !e->coop)) return MIOSQP_EARG;
+  ENTER(e);
   unsigned long long *buf = nullptr;
   HIPCHK(hipMalloc((void **)&buf, sizeof(unsigned long long) * 2 * 8192));
-  HIPCHK(hipMemset(buf, 0, sizeof(unsigned long long) * 2 * 8192));
+  HIPCHK(hipMemsetAsync(buf, 0, sizeof(unsigned long long) * 2 * 8192, e->stream));
   for (int i = 0; i < 20; i++) launch_iteration(e);
   Dev saved = e->d;
   e->d.prof = buf;
@@ -713,6 +732,7 @@ int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, 
 // debug: shader cycles and 100 MHz wall ticks recorded by the last LDS-resident launch
 int miosqp_qp_debug_clock(miosqp_qp_engine *e, double *cycles, double *ticks) {
   if (!e) return MIOSQP_EARG;
+  ENTER(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   Ctrl c;
   HIPCHK(hipMemcpy(&c, e->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
@@ -742,6 +762,7 @@ int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_it
 
 int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, double *usec, double *bytes) {
   if (!e || which < 0 || (which > 4 && which < 10) || which > 14 || reps <= 0 || !usec) return MIOSQP_EARG;
+  ENTER(e);
   if (which >= 10 && e->Bcap == 0) {
     g_err = "time_kernel: batched kernels need a prior solve_batch";
     return MIOSQP_EARG;

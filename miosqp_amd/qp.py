@@ -159,7 +159,8 @@ class OSQP(object):
         digest = None
         if info.int_inf >= 0:
             digest = types.SimpleNamespace(int_inf=info.int_inf, nextvar=info.nextvar,
-                                           heur_feasible=info.heur_viol <= 0.0, heur_obj=info.heur_obj)
+                                           heur_feasible=info.heur_viol <= 0.0, heur_obj=info.heur_obj,
+                                           info_viol=info.heur_viol)
         return types.SimpleNamespace(x=x, y=y, status_val=info.status_val, iter=info.iter,
                                      run_time=info.run_time, lower=lower, info=info, digest=digest)
 
@@ -181,7 +182,8 @@ class OSQP(object):
         for k, i in enumerate(infos):
             if i.int_inf >= 0:
                 digests[k] = types.SimpleNamespace(int_inf=i.int_inf, nextvar=i.nextvar,
-                                                   heur_feasible=i.heur_viol <= 0.0, heur_obj=i.heur_obj)
+                                                   heur_feasible=i.heur_viol <= 0.0, heur_obj=i.heur_obj,
+                                                   info_viol=i.heur_viol)
         return types.SimpleNamespace(
             digest=digests,
             x=x, y=y, status_val=np.array([i.status_val for i in infos]),

@@ -207,12 +207,16 @@ def test_config2_full_size_root_and_children(oracle_mod):
     ro = o.solve()
     assert (rg.status_val, rg.iter) == (ro.info.status_val, ro.info.iter)
     assert rel(rg.y, ro.y) <= SOL_TOL
+    ii, p_int = pr["i_idx"], len(pr["i_idx"])
+    cont = np.setdiff1d(np.arange(n), ii)
+    xo = ro.x.copy()
+    xo[ii] = np.minimum(np.maximum(xo[ii], l[-p_int:]), u[-p_int:])  # node.py:131-136
+    assert rel(rg.x[cont], ro.x[cont]) <= SOL_TOL and rel(rg.x, xo) <= SOL_TOL
     c = kkt_certificate(pr["P"], pr["q"], A, l, u, ro.x, ro.y)
     zc = np.clip(A.dot(ro.x), l, u)
     ep, ed = osqp_tolerances(pr["P"], pr["q"], A, ro.x, ro.y, zc, 1e-3, 1e-3)
     assert c["pri"] <= ep and c["dua"] <= ed
     # branch on the most fractional integer like workspace.py:205-230
-    ii = pr["i_idx"]
     xi = rg.x[ii]
     k = int(np.argmax(np.abs(xi - np.round(xi))))
     for side in (0, 1):
@@ -227,6 +231,11 @@ def test_config2_full_size_root_and_children(oracle_mod):
         ro2 = o.solve()
         assert (r2.status_val, r2.iter) == (ro2.info.status_val, ro2.info.iter)
         assert rel(r2.y, ro2.y) <= SOL_TOL
+        xo2 = ro2.x.copy()
+        xo2[ii] = np.minimum(np.maximum(xo2[ii], l2[-p_int:]), u2[-p_int:])
+        assert rel(r2.x[cont], ro2.x[cont]) <= SOL_TOL and rel(r2.x, xo2) <= SOL_TOL
+        lo2 = 0.5 * xo2.dot(pr["P"].dot(xo2)) + pr["q"].dot(xo2)
+        assert abs(r2.lower - lo2) <= 1e-9 * max(1.0, abs(lo2))
 
 
 def _wave_of_nodes(oracle_mod, pr, count):
@@ -323,6 +332,123 @@ def test_batch_equals_node_by_node(oracle_mod, n, m, p, seed, count, fold, cap):
     rb2 = g.solve_batch(L, U, X, Y)
     np.testing.assert_array_equal(rb.x, rb2.x)
     np.testing.assert_array_equal(rb.iter, rb2.iter)
+
+
+def _frontier(g, pr, l, u, width):
+    """Level-by-level expansion of the tree from the root (every leaf of a level is solved node-at-a-time
+    and branched floor / ceil on the digest's branching variable, children warm-started from the parent,
+    workspace.py:157-203) until at least `width` leaves are open -- the kind of frontier bench.py's batched
+    leg works on.  Nothing is pruned, so the wave mixes cheap and expensive, feasible and infeasible leaves."""
+    import types
+    m, ii = pr["A"].shape[0], pr["i_idx"]
+    n, M = len(pr["q"]), len(l)
+    nodes = [types.SimpleNamespace(l=l.copy(), u=u.copy(), x=np.zeros(n), y=np.zeros(M))]
+    while 0 < len(nodes) < width:
+        level, nodes = nodes, []
+        for nd in level:
+            r = g.solve_node(nd.l, nd.u, nd.x, nd.y)
+            if r.status_val != 1 or r.digest is None or r.digest.int_inf == 0:
+                continue
+            v = r.digest.nextvar
+            xv = r.x[ii[v]]
+            for side in (0, 1):
+                l2, u2 = nd.l.copy(), nd.u.copy()
+                if side == 0:
+                    u2[m + v] = np.floor(xv)
+                else:
+                    l2[m + v] = np.ceil(xv)
+                nodes.append(types.SimpleNamespace(l=l2, u=u2, x=r.x, y=r.y))
+    return nodes
+
+
+def _check_wave(g, o, pr, A, l, u, leaves, sample, want_compaction):
+    """solve_batch(wave) == solve_node on every leaf (status, iterations, x, y, lower, digest) and == the
+    oracle on every `sample`-th leaf; returns the per-leaf solve_node results."""
+    L = np.stack([lf.l for lf in leaves]); U = np.stack([lf.u for lf in leaves])
+    X = np.stack([lf.x for lf in leaves]); Y = np.stack([lf.y for lf in leaves])
+    ii, p_int = pr["i_idx"], len(pr["i_idx"])
+    c0 = g.compactions()
+    rb = g.solve_batch(L, U, X, Y)
+    if want_compaction:
+        assert g.compactions() > c0  # columns finish at different tests: the wave was compacted
+    singles = []
+    for k in range(len(leaves)):
+        r1 = g.solve_node(L[k], U[k], X[k], Y[k])
+        singles.append(r1)
+        assert (rb.status_val[k], rb.iter[k]) == (r1.status_val, r1.iter), k
+        if r1.status_val in (1, -2):
+            assert rel(rb.x[k], r1.x) <= SOL_TOL and rel(rb.y[k], r1.y) <= SOL_TOL, k
+            assert abs(rb.lower[k] - r1.lower) <= 1e-9 * max(1.0, abs(r1.lower)), k
+            db, d1 = rb.digest[k], r1.digest
+            assert db.int_inf == d1.int_inf, k
+            frac = np.abs(r1.x[ii] - np.round(r1.x[ii]))
+            srt = np.sort(frac)
+            if srt[-1] - srt[-2] > 1e-7:  # a clear winner: the branching variable cannot depend on rounding
+                assert db.nextvar == d1.nextvar == int(np.argmax(frac)), k
+            if abs(d1.info_viol) > 1e-7:
+                assert db.heur_feasible == d1.heur_feasible, k
+            assert abs(db.heur_obj - d1.heur_obj) <= 1e-9 * max(1.0, abs(d1.heur_obj)), k
+        else:
+            assert np.isnan(rb.lower[k]) and rb.digest[k] is None
+        if k % sample == 0:
+            o.update(l=L[k], u=U[k])
+            o.warm_start(x=X[k], y=Y[k])
+            ro = o.solve()
+            assert (rb.status_val[k], rb.iter[k]) == (ro.info.status_val, ro.info.iter), k
+            if ro.info.status_val in (1, -2):
+                xo = ro.x.copy()
+                xo[ii] = np.minimum(np.maximum(xo[ii], L[k][-p_int:]), U[k][-p_int:])
+                assert rel(rb.x[k], xo) <= SOL_TOL and rel(rb.y[k], ro.y) <= SOL_TOL, k
+                lo = 0.5 * xo.dot(pr["P"].dot(xo)) + pr["q"].dot(xo)
+                assert abs(rb.lower[k] - lo) <= 1e-9 * max(1.0, abs(lo)), k
+    rb2 = g.solve_batch(L, U, X, Y)  # bit-identical rerun
+    np.testing.assert_array_equal(rb.x, rb2.x)
+    np.testing.assert_array_equal(rb.y, rb2.y)
+    np.testing.assert_array_equal(rb.iter, rb2.iter)
+    return singles
+
+
+def test_config3_full_size_wave_of_256_leaves(oracle_mod):
+    """BASELINE config 3: random_miqp n=500 m=1000 p=250, 256 open leaves in ONE batched device call
+    (four 64-column tiles, compacted as columns finish), then their children -- more than 256 leaves, up
+    to eight tiles -- on an engine with capacity 1024."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
+    A, l, u = problems.extended(pr)
+    m = pr["A"].shape[0]
+    g = qp.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **dict(problems.QP_SETTINGS, max_batch=256))
+    g.set_integer_rows(pr["i_idx"], m)
+    g.set_root(l, u, 1e-3, 1e-3)
+    leaves = _frontier(g, pr, l, u, 256)[:256]
+    assert len(leaves) == 256
+    o = oracle_mod.OSQP()
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    singles = _check_wave(g, o, pr, A, l, u, leaves, 8, True)   # 32 leaves against the oracle
+    iters = np.array([r.iter for r in singles])
+    assert iters.min() < iters.max()  # a real wave: leaves need different numbers of tests
+    # children of the wave (floor / ceil on the digest's branching variable, warm-started from the parent)
+    import types
+    kids = []
+    for lf, r in zip(leaves, singles):
+        if r.status_val != 1 or r.digest is None or r.digest.int_inf == 0:
+            continue
+        v = r.digest.nextvar
+        xv = r.x[pr["i_idx"][v]]
+        for side in (0, 1):
+            l2, u2 = lf.l.copy(), lf.u.copy()
+            if side == 0:
+                u2[m + v] = np.floor(xv)
+            else:
+                l2[m + v] = np.ceil(xv)
+            kids.append(types.SimpleNamespace(l=l2, u=u2, x=r.x, y=r.y))
+    kids = kids[:448]
+    assert len(kids) > 256
+    g2 = qp.OSQP()
+    g2.setup(pr["P"], pr["q"], A, l, u, **dict(problems.QP_SETTINGS, max_batch=1024))
+    g2.set_integer_rows(pr["i_idx"], m)
+    g2.set_root(l, u, 1e-3, 1e-3)
+    _check_wave(g2, o, pr, A, l, u, kids, 28, True)             # 16 more against the oracle
 
 
 def test_batched_search_finds_the_same_optimum():
