@@ -14,6 +14,14 @@ P and A -- hence the factor -- and draws new q, l, u, through MIOSQP.update_vect
 y0: 34 KB) are part of the path and travel inside it.  N > 1 shards the open leaves over the
 ranks (miosqp_amd/dist.py), one process per GPU, RCCL only for the incumbent: weak scaling.
 
+Extra legs in the same JSON line (none of them is part of `value`):
+  batched   BASELINE configs[2]: waves of up to 256 leaves per device call
+  stream    the same node-at-a-time workload on the HBM-STREAMING form of the engine (factor re-read from
+            HBM every iteration, two launches per iteration) -- what the north star's roofline is about
+  config5   BASELINE configs[4]: n=5000, the bandwidth-bound single-node case
+  config4   BASELINE configs[3]: the power-converter MPC sequence (40 MIQPs, n=18)
+  cpu_baseline  the reference's CPU path (real OSQP when importable, else the oracle) on this box's host cores
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -29,38 +37,58 @@ sys.path.insert(0, ROOT)
 
 KERNELS = ["k_panel_fwd", "k_tail_fwd", "k_tail_bwd", "k_panel_bwd"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+ALL_LEGS = ("batched", "stream", "config5", "config4", "cpu")
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/
-    r*_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
+def pmc_traffic(kernel, tag=""):
+    """HBM-side bytes per launch of `kernel` from the newest COMMITTED rocprofv3 PMC summary
+    profiles/r*_pmc_traffic<tag>.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the
+    gfx950 correction); (bytes, file) or (None, None).  Not measured in this run: counters need the profiler."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic%s.json" % tag)))
     if not files:
-        return None
+        return None, None
     try:
         kernels = json.load(open(files[-1]))["kernels"]
         for name in sorted(kernels):  # template instances are listed as "name<...>"
             if name == kernel or name.startswith(kernel + "<"):
-                return kernels[name]["traffic_bytes"]
-        return None
+                return kernels[name]["traffic_bytes"], "profiles/" + os.path.basename(files[-1])
     except Exception:
-        return None
+        pass
+    return None, None
 
 
-def large_leg(seed, nodes=12):
-    """Extra leg, not part of `value`: BASELINE configs[4] (random_miqp n=5000 m=10000 p=2500, 1 % dense
-    A, fp64), where the single-node iteration is HBM-bandwidth-bound (317 MB algorithmic per iteration)."""
-    from miosqp_amd import bnb, dist, problems
+def host_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(cpu_model=model, nproc=os.cpu_count())
+
+
+def setup_model(prob, qs, st=None, backend=None):
+    from miosqp_amd import bnb, problems
+    st = dict(problems.BNB_SETTINGS) if st is None else st
+    st["max_iter_bb"] = 10 ** 9  # fixed node budget comes from --steps, not from the tree
+    model = bnb.MIOSQP(backend=backend)
+    t0 = time.time()
+    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"], prob["i_u"], st, qs)
+    return model, time.time() - t0
+
+
+def large_leg(seed, device, nodes=12):
+    """BASELINE configs[4] (random_miqp n=5000 m=10000 p=2500, 1 % dense A, fp64): the single-node iteration
+    is HBM-bandwidth-bound.  Two byte conventions side by side: SURVEY sec. 8d's (12 B per factor entry, value +
+    index: 317 MB per iteration) and what the kernels really request (the dense tail has no index array: 8 B
+    per entry, ~217 MB)."""
+    from miosqp_amd import dist, problems
     cfg = problems.CONFIGS["cfg5"]
     prob = problems.random_miqp(seed=seed, **cfg)
-    st = dict(problems.BNB_SETTINGS)
-    st["max_iter_bb"] = 10 ** 9
-    model = bnb.MIOSQP()
-    t0 = time.time()
-    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"], prob["i_u"], st,
-                dict(problems.QP_SETTINGS))
-    setup_s = time.time() - t0
+    model, setup_s = setup_model(prob, dict(problems.QP_SETTINGS, device=device))
     eng = model.work.solver
     srch = dist.ShardedSearch(model)
     srch.step(1)
@@ -72,34 +100,153 @@ def large_leg(seed, nodes=12):
     dt = time.perf_counter() - t0
     ms, it = eng.loop_stats()
     fs = eng.factor_stats()
-    gbs = fs["bytes_per_iter"] * it / max(1e-9, ms) * 1e-6
-    return dict(workload="random_miqp n=%d m=%d p=%d density %.2f, node-at-a-time" %
-                         (cfg["n"], cfg["m"], cfg["p"], cfg["density"]),
-                iters_per_s=round((srch.iters - i0) / dt, 1), nodes_per_s=round((srch.nodes - n0) / dt, 2),
-                nnz_L=fs["nnz_L"], setup_s=round(setup_s, 2), bytes_per_iter=fs["bytes_per_iter"],
-                usec_per_iter=round(1e3 * ms / max(1, it), 2), achieved_gbs=round(gbs, 1),
-                frac=round(gbs / HBM_PEAK_GBS, 4), factor_form="L (4 launches/iteration)")
+    us = 1e3 * ms / max(1, it)
+    kern = []
+    for k, nm in enumerate(KERNELS):
+        kus, kby = eng.time_kernel(k, 100)
+        kern.append(dict(kernel=nm, usec=round(kus, 2), bytes_sec8d=kby))
+    tr, src = pmc_traffic("k_tail_fwd", "_cfg5")
+    out = dict(workload="random_miqp n=%d m=%d p=%d density %.2f, node-at-a-time" %
+                        (cfg["n"], cfg["m"], cfg["p"], cfg["density"]),
+               iters_per_s=round((srch.iters - i0) / dt, 1), nodes_per_s=round((srch.nodes - n0) / dt, 2),
+               nnz_L=fs["nnz_L"], setup_s=round(setup_s, 2), usec_per_iter=round(us, 2),
+               bytes_per_iter=fs["bytes_per_iter"], achieved_gbs=round(fs["bytes_per_iter"] / us * 1e-3, 1),
+               frac=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
+               bytes_moved_per_iter=fs["bytes_moved_per_iter"],
+               moved_gbs=round(fs["bytes_moved_per_iter"] / us * 1e-3, 1),
+               moved_frac=round(fs["bytes_moved_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
+               bound="hbm", factor_form="L (4 launches/iteration)", kernels_back_to_back=kern,
+               note="frac uses SURVEY 8d's 12 B per factor entry; moved_frac the 8 B per entry the dense tail "
+                    "kernels really request")
+    if tr is not None:
+        out["pmc_traffic_k_tail_fwd"] = dict(bytes_per_launch=tr, source=src)
+    eng.close()
+    return out
+
+
+def stream_leg(prob, device, nodes=40):
+    """The HBM-streaming form of the engine on the headline workload: product-form factor stored once in HBM and
+    re-read by every iteration (k_fold_fwd / k_fold_bwd, two launches per iteration).  This is the form the
+    north star's "achieved HBM GB/s against the 8 TB/s roofline" is about, the form every problem with
+    n + M > 2048 runs in, and what a cooperative engine falls back to on a shared device."""
+    from miosqp_amd import dist, problems
+    model, setup_s = setup_model(prob, dict(problems.QP_SETTINGS, device=device, coop=0))
+    eng = model.work.solver
+    srch = dist.ShardedSearch(model)
+    for _ in range(5):
+        srch.step(1)
+    eng.loop_stats(reset=True)
+    n0, i0 = srch.nodes, srch.iters
+    t0 = time.perf_counter()
+    for _ in range(nodes):
+        if srch.step(1) == 0:
+            break
+    dt = time.perf_counter() - t0
+    ms, it = eng.loop_stats()
+    fs = eng.factor_stats()
+    us = 1e3 * ms / max(1, it)
+    kern = []
+    for k, nm in enumerate(["k_fold_fwd", "k_fold_bwd"]):
+        kus, kby = eng.time_kernel(k, 300)
+        tr, src = pmc_traffic(nm, "_two_kernel_form")
+        rec = dict(kernel=nm, usec=round(kus, 3), bytes=kby, gbs=round(kby / kus * 1e-3, 1))
+        if tr is not None:
+            rec.update(traffic=tr, hbm_measured_gbs=round(tr / kus * 1e-3, 1), traffic_source=src)
+        kern.append(rec)
+    out = dict(workload="the headline workload on the HBM-streaming engine form (coop=0)",
+               factor_form="product form L^-1 in HBM, 2 launches/iteration", bound="hbm",
+               iters_per_s=round((srch.iters - i0) / dt, 1), nodes_per_s=round((srch.nodes - n0) / dt, 2),
+               usec_per_iter=round(us, 3), bytes_per_iter=fs["bytes_per_iter"],
+               achieved_gbs=round(fs["bytes_per_iter"] / us * 1e-3, 1),
+               frac=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4), kernels_back_to_back=kern,
+               setup_s=round(setup_s, 3))
+    eng.close()
+    return out
+
+
+def mpc_leg(device, repeats=3):
+    """BASELINE configs[3]: the power-converter MPC sequence (horizon N=3, n=18, 45 rows): 40 consecutive MIQPs
+    sharing one factorisation through update_vectors + set_x0, replayed from the committed fixture exactly as
+    the reference's closed loop drives MIOSQP (power_converter.py:467-476).  Many tiny sequential nodes
+    (~50 iterations each): latency, not bandwidth -- reported as time per node / per MPC step."""
+    from miosqp_amd import problems, qp
+    pc = problems.load_power_converter()
+    pc["qp_settings"] = dict(pc["qp_settings"], device=device)
+    recs, model = problems.run_power_converter(pc, qp)  # warm-up + parity check
+    ok = all(r["nodes"] == int(pc["nodes"][k]) and r["osqp_iter"] == int(pc["osqp_iter"][k])
+             for k, r in enumerate(recs))
+    eng = model.work.solver
+    eng.loop_stats(reset=True)
+    nodes = iters = 0
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        recs, model = problems.run_power_converter(pc, qp, model=model)
+        nodes += sum(r["nodes"] for r in recs)
+        iters += sum(r["osqp_iter"] for r in recs)
+    dt = time.perf_counter() - t0
+    ms, it = eng.loop_stats()
+    fs = eng.factor_stats()
+    steps = repeats * len(recs)
+    out = dict(workload="power_converter MPC N=3 (n=18, 45 rows), %d MPC steps replayed %d times" % (len(recs), repeats),
+               engine_form="LDS-resident single workgroup" if fs["resident"] else
+                           "cooperative" if fs["coop"] else "multi-kernel",
+               mpc_steps_per_s=round(steps / dt, 1), nodes_per_s=round(nodes / dt, 1),
+               iters_per_s=round(iters / dt, 1), usec_per_node=round(1e6 * dt / max(1, nodes), 1),
+               usec_per_mpc_step=round(1e6 * dt / steps, 1), nodes_per_mpc_step=round(nodes / steps, 2),
+               iters_per_node=round(iters / max(1, nodes), 1),
+               device_usec_per_iter=round(1e3 * ms / max(1, it), 3),
+               device_usec_per_node=round(1e3 * ms / max(1, nodes), 1),
+               matches_reference_fixture=bool(ok),
+               bound="latency (8 KB of factor: LDS-resident, the HBM roofline does not apply)")
+    eng.close()
+    return out
 
 
 def cpu_baseline(prob, budget_s):
-    """The CPU oracle ("port": own restatement, NOT the real OSQP which is absent) on the same tree,
-    one thread, bounded to about `budget_s` seconds."""
+    """The reference's CPU path on this box's host cores, bounded to about `budget_s` seconds of the same tree.
+    Probes `import osqp` first: if the real package is present the tree search runs on it
+    (kind "reference", with the frozen spec's parameters so that both sides do the same work); otherwise on
+    the CPU oracle (kind "port": own restatement of the algorithm, NOT OSQP).  One thread either way: OSQP's
+    QDLDL path and the oracle are sequential codes."""
     from miosqp_amd import bnb, dist, problems
-    from oracle import oracle
-    st = dict(problems.BNB_SETTINGS)
-    st["max_iter_bb"] = 10 ** 9
-    model = bnb.MIOSQP(backend=oracle)
-    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"],
-                prob["i_u"], st, dict(problems.QP_SETTINGS))
+    info = host_info()
+    kind, backend, why = "port", None, ""
+    try:
+        import osqp  # noqa: F401  (/root/reference/miosqp/node.py:2)
+        if hasattr(osqp, "constant") and hasattr(osqp, "OSQP"):
+            backend, kind = osqp, "reference"
+        else:
+            why = "an `osqp` module is importable but lacks the 0.6-era surface (constant/OSQP) the reference uses"
+    except Exception as e:  # absent on the GPU box: it receives only this repository
+        why = "import osqp failed (%s)" % type(e).__name__
+    qs = dict(problems.QP_SETTINGS)
+    if backend is None:
+        from oracle import oracle
+        backend = oracle
+    else:
+        qs.update(rho=0.1, sigma=1e-6, alpha=1.6, adaptive_rho=False, max_iter=4000, scaling=10,
+                  check_termination=25, polish=False, eps_dual_inf=1e-4)
+    try:
+        model, _ = setup_model(prob, qs, backend=backend)
+    except Exception as e:
+        if kind == "reference":  # e.g. an osqp >= 1.0 whose keyword names differ: fall back, and say so
+            from oracle import oracle
+            why = "real osqp present but its setup() refused the reference's call (%s)" % type(e).__name__
+            kind, backend, qs = "port", oracle, dict(problems.QP_SETTINGS)
+            model, _ = setup_model(prob, qs, backend=backend)
+        else:
+            raise
     srch = dist.ShardedSearch(model)
     t0 = time.time()
     while time.time() - t0 < budget_s and model.work.leaves:
         srch.step(1)
     dt = time.time() - t0
-    return dict(value=srch.iters / dt, unit="ADMM iter/s", cores=1, kind="port",
-                nodes_per_s=srch.nodes / dt,
-                sample="first %d nodes (%d ADMM iterations, %.1f s) of the same tree, oracle/qp_oracle.c "
-                       "single thread; real OSQP is not installed" % (srch.nodes, srch.iters, dt))
+    what = "real OSQP %s" % getattr(backend, "__version__", "?") if kind == "reference" else \
+        "oracle/qp_oracle.c (own CPU restatement, not OSQP; %s)" % why
+    return dict(value=srch.iters / dt, unit="ADMM iter/s", cores=1, kind=kind, nodes_per_s=srch.nodes / dt,
+                cpu_model=info["cpu_model"], nproc=info["nproc"],
+                sample="first %d nodes (%d ADMM iterations, %.1f s) of the same tree, one thread of %d host cores; %s"
+                       % (srch.nodes, srch.iters, dt, info["nproc"] or 0, what))
 
 
 def main():
@@ -121,14 +268,27 @@ def main():
     ap.add_argument("--batch-waves", type=int, default=12)
     ap.add_argument("--no-large-leg", action="store_true",
                     help="skip the extra BASELINE configs[4] leg (n=5000, bandwidth-bound single-node ADMM)")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="skip the back-to-back kernel timing launches (profiling runs: every dispatch of the hot "
+                         "kernel is then a node relaxation of the timed workload)")
+    ap.add_argument("--legs", default="all",
+                    help="comma list of extra legs to run: batched,stream,config5,config4,cpu ('none' = headline only)")
     args = ap.parse_args()
+    legs = set(ALL_LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
+    if args.no_cpu_baseline:
+        legs.discard("cpu")
+    if args.no_large_leg:
+        legs.discard("config5")
+    if args.batch_width <= 0:
+        legs.discard("batched")
 
     import torch
-    from miosqp_amd import bnb, dist, problems
+    from miosqp_amd import dist, problems
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the relaxation engine has no CPU fallback")
     # MIOSQP_BENCH_ONE_DEVICE=1: every rank uses GPU 0 and the collectives run over gloo (CPU tensors);
@@ -141,7 +301,10 @@ def main():
         os.environ.setdefault("MIOSQP_COOP", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    td = None
+    if world > 1 or launched:
+        # also with ONE rank when launched through torch.distributed.run: the process group is RCCL and the
+        # barrier / all-reduce / all-gather below run on device tensors exactly as they do with 8 ranks
         import torch.distributed as td
         if one_dev:
             td.init_process_group(backend="gloo")
@@ -156,27 +319,22 @@ def main():
 
     cfg = problems.CONFIGS[args.config]
     prob = problems.random_miqp(seed=args.seed, **cfg)
-    st = dict(problems.BNB_SETTINGS)
-    st["max_iter_bb"] = 10 ** 9  # fixed node budget comes from --steps, not from the tree
     qs = dict(problems.QP_SETTINGS)
     qs["device"] = local_rank
     qs["max_batch"] = max(64, args.batch_width)
-    model = bnb.MIOSQP()
-    t_setup = time.time()
-    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"],
-                prob["i_u"], st, qs)
-    t_setup = time.time() - t_setup
+    model, t_setup = setup_model(prob, qs)
     eng = model.work.solver
     srch = dist.ShardedSearch(model, comm)
     m_orig = cfg["m"]
     rng = np.random.RandomState(args.seed + 12345)
-    stream = dict(instances=1)
+    stream = dict(instances=1, closed=[])  # closed: (time, global nodes of that tree) per closed tree
 
     def next_instance():
         """The tree closed: re-root on the next MIQP of the stream.  Same P and A, hence the same
         factor in HBM; new q, l, u drawn like the generator draws them (run_example.py:76-80), pushed
         through MIOSQP.update_vectors exactly like the reference's MPC loop does
         (/root/reference/miosqp/solver.py:174-205).  Every rank draws the same numbers."""
+        stream["closed"].append((time.perf_counter(), srch.global_nodes))
         q = rng.randn(cfg["n"])
         u = 2 + rng.rand(m_orig)
         l = -2 + rng.rand(m_orig)
@@ -202,6 +360,7 @@ def main():
     sync()
     eng.loop_stats(reset=True)
     n0, i0, inst0 = srch.nodes, srch.iters, stream["instances"]
+    del stream["closed"][:]
     t0 = time.perf_counter()
     run_steps(args.steps, args.wave, False)
     srch.drain()  # the exchange still in flight belongs to the timed region
@@ -211,18 +370,26 @@ def main():
     nodes_here = srch.nodes - n0
     tot = comm.sum([srch.iters - i0, srch.nodes - n0, dt])
     dt_max = dt
-    if world > 1:
-        import torch.distributed as td
+    if td is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm.device)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt_max = float(tmax.item())
     iters, nodes = float(tot[0]), float(tot[1])
     instances = stream["instances"] - inst0 + 1
+    # time to close a tree: what branch and bound buys.  Speculative nodes of a parallel search count in `value`
+    # (work per second) but only shorten this if they were useful.
+    closed = list(stream["closed"])
+    trees = dict(closed_in_timed_region=len(closed))
+    if len(closed) >= 2:
+        gaps = [closed[k][0] - closed[k - 1][0] for k in range(1, len(closed))]
+        trees.update(mean_ms_to_close=round(1e3 * float(np.mean(gaps)), 3),
+                     mean_nodes_per_tree=round(float(np.mean([c[1] for c in closed[1:]])), 1),
+                     trees_per_s=round(1.0 / float(np.mean(gaps)), 2))
 
     # ---- extra leg (BASELINE configs[2]): the same stream explored in waves of up to `batch_width`
     #      leaves per rank, each wave ONE batched device call (not part of `value`) -------------------
     batched = None
-    if args.batch_width > 0:
+    if "batched" in legs:
         next_instance()
         run_steps(12, args.batch_width, True)  # warm-up: graph capture, allocation, frontier ramp-up
         sync()
@@ -235,7 +402,7 @@ def main():
         dtb = time.perf_counter() - t1
         bms, bit, bnode = eng.batch_stats()
         totb = comm.sum([srch.iters - i1, srch.nodes - n1])
-        if world > 1:
+        if td is not None:
             tb = torch.tensor([dtb], dtype=torch.float64, device=comm.device)
             td.all_reduce(tb, op=td.ReduceOp.MAX)
             dtb = float(tb.item())
@@ -244,6 +411,8 @@ def main():
                        node_iters_per_s=round(float(totb[0]) / dtb, 1), nodes_per_s=round(float(totb[1]) / dtb, 2),
                        lockstep_iters=bit, device_us_per_lockstep_iter=round(1e3 * bms / max(1, bit), 2),
                        device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
+        batched["end_to_end_over_device"] = round(batched["node_iters_per_s"] /
+                                                  max(1.0, batched["device_node_iters_per_s"] * world), 3)
 
     if rank == 0:
         fs = eng.factor_stats()
@@ -255,17 +424,32 @@ def main():
             us, by = 1e3 * loop_ms / launches, fs["bytes_per_iter"] * loop_iters / launches
             kern.append(dict(kernel="k_coop", usec=round(us, 3), bytes=round(by), gbs=round(by / us * 1e-3, 1),
                              launches=launches, iterations_per_launch=round(loop_iters / launches, 1)))
-            it_us, it_bytes = eng.time_kernel(4, 2000)
+            it_us, it_bytes = (0.0, 0.0) if args.no_probes else eng.time_kernel(4, 2000)
         else:
             names = ["k_fold_fwd", "k_fold_bwd"] if fs["fold"] else KERNELS
-            for k, nm in enumerate(names):
-                us, by = eng.time_kernel(k, 300)
-                kern.append(dict(kernel=nm, usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
-            it_us, it_bytes = eng.time_kernel(4, 100)
+            if args.no_probes:  # no extra launches: the whole iteration from the loop's own events
+                us = 1e3 * loop_ms / max(1, loop_iters)
+                kern.append(dict(kernel="+".join(names), usec=round(us, 3), bytes=fs["bytes_per_iter"],
+                                 gbs=round(fs["bytes_per_iter"] / max(1e-9, us) * 1e-3, 1)))
+                it_us = us
+            else:
+                for k, nm in enumerate(names):
+                    us, by = eng.time_kernel(k, 300)
+                    kern.append(dict(kernel=nm, usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
+                it_us, it_bytes = eng.time_kernel(4, 100)
         dom = max(kern, key=lambda d: d["usec"])
-        roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom["kernel"]),
-                    traffic_source="profiles/r*_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
+        traffic, tsrc = pmc_traffic(dom["kernel"])
+        # What binds the dominant kernel.  `achieved` / `frac` follow the contract: ALGORITHMIC bytes (SURVEY
+        # sec. 8d's per-iteration figure x iterations per launch) over the measured launch time against the HBM
+        # peak.  For the cooperative solver those bytes never leave the register file after the first
+        # iteration, so the kernel is bound by its one all-to-all hand-off per iteration, not by HBM:
+        # `hbm_measured_gbs` (PMC traffic / time) is what HBM really delivers.
+        roof = dict(bound="exchange-latency" if fs["coop"] else "hbm",
+                    roofline="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic,
+                    traffic_source=("committed profile %s (separate rocprofv3 --pmc passes of a node-only run; "
+                                    "not measured in this run)" % tsrc) if tsrc else None,
+                    hbm_measured_gbs=round(traffic / dom["usec"] * 1e-3, 1) if traffic else None,
                     bytes_per_launch=dom["bytes"], usec_per_launch=dom["usec"], kernels=kern,
                     iteration=dict(bytes=fs["bytes_per_iter"],
                                    usec_in_timed_region=round(1e3 * loop_ms / max(1, loop_iters), 3),
@@ -273,13 +457,17 @@ def main():
                                    achieved=round(fs["bytes_per_iter"] * loop_iters / max(1e-9, loop_ms) * 1e-6, 1),
                                    frac=round(fs["bytes_per_iter"] * loop_iters / max(1e-9, loop_ms) * 1e-6 /
                                               HBM_PEAK_GBS, 4)),
-                    timing="HIP events on the engine's stream")
+                    timing="HIP events on the engine's stream",
+                    note="the factor is register-resident in this form (explicit KKT inverse spread over the CUs): "
+                         "`achieved` counts algorithmic bytes, `hbm_measured_gbs` what HBM delivered; the "
+                         "HBM-streaming form of the same workload is the `stream` leg" if fs["coop"] else None)
         out = dict(metric="ADMM iterations/s (random_miqp n=%d m=%d p=%d, node-at-a-time B&B)" %
                           (cfg["n"], cfg["m"], cfg["p"]),
                    value=round(iters / dt_max, 1), unit="ADMM iter/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(1e3 * dt_max / args.steps, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                    nodes_per_s=round(nodes / dt_max, 2), iters_per_node=round(iters / max(1.0, nodes), 1),
+                   nodes=nodes, trees=trees,
                    config=dict(workload="BASELINE configs[1]: random_miqp n=%d m=%d p=%d density %.2f seed %d, "
                                         "%s per rank per step, leaves sharded over %d GPU(s)" %
                                         (cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed,
@@ -289,7 +477,9 @@ def main():
                                factor_form="explicit KKT inverse in registers, cooperative launch per node"
                                if fs["coop"] else "product form L^-1 (2 launches/iteration)" if fs["fold"]
                                else "L (4 launches/iteration)",
-                               qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3)),
+                               qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3),
+                               coop_fallbacks=fs["coop_fallbacks"], replicated_resyncs=srch.resyncs,
+                               comm=type(comm).__name__ + ("/nccl" if (td is not None and not one_dev) else "")),
                    roofline=roof)
         out["config"]["instances_in_timed_region"] = instances
         if batched is not None and batched["lockstep_iters"] > 0:
@@ -300,13 +490,17 @@ def main():
                 bk.append(dict(kernel=nm, usec=round(us, 2), bytes=by, gbs=round(by / us * 1e-3, 1)))
             batched["kernels"] = bk
             out["batched"] = batched
-        if world == 1 and not args.no_large_leg and args.config == "cfg2":
-            out["config5"] = large_leg(args.seed)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and args.config == "cfg2":
+            if "stream" in legs:
+                out["stream"] = stream_leg(prob, local_rank)
+            if "config5" in legs:
+                out["config5"] = large_leg(args.seed, local_rank)
+            if "config4" in legs:
+                out["config4"] = mpc_leg(local_rank)
+        if world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as td
+    if td is not None:
         td.barrier()
         td.destroy_process_group()
 

@@ -166,7 +166,9 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
  * out[3]=algorithmic bytes per ADMM iteration (SURVEY.md sec. 8d formula), out[4..6] threads per
  * row of the panel/tail kernels, out[7] bit 0 = product-form factor in use, bit 1 = LDS-resident solver in use,
  * bit 2 = dense setup stages ran on the device, bit 3 = cooperative solver in use, bits 8..15 = its calibrated
- * poll delay (64-clock units) */
+ * poll delay (64-clock units); out[8] = bytes per iteration the kernels of the form in use actually request (dense
+ * blocks carry no index array: 8 B per entry instead of the formula's 12); out[9] = times the engine fell back from
+ * the cooperative form.  out must hold 10 values. */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
 
 /* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's

@@ -314,7 +314,14 @@ class Workspace(object):
             return
         dg = leaf.digest
         if dg is not None:
-            # same decisions from the device digest of this node's x
+            # Same decisions from the device digest of this node's x.  The device sums in another order than
+            # numpy, so its objective values agree with the host's to ~1e-12 relative, not bit for bit; what
+            # enters `upper_glob` through the rounding heuristic is therefore recomputed on the host (rare:
+            # only when the digest says the incumbent improves), exactly as workspace.py:321-327 computes
+            # it.  `leaf.lower` is the device value on this path by design (node.py:143 fused into the
+            # epilogue; 1e-9 relative, DESIGN.md "tolerances").
+            if self.settings['branching_rule'] != 0:
+                raise ValueError('No variable selection rule recognized!')
             leaf.intinf = dg.int_inf
             if dg.int_inf == 0:
                 leaf.frac_idx = []
@@ -323,9 +330,14 @@ class Workspace(object):
                 self.prune()
                 return
             if dg.heur_feasible and dg.heur_obj < self.upper_glob:
-                self.upper_glob = dg.heur_obj
-                self.x = self.get_integer_solution(leaf.x)
-                self.prune()
+                x_int = self.get_integer_solution(leaf.x)
+                obj_int = self.data.compute_obj_val(x_int)
+                if obj_int < self.upper_glob:
+                    self.upper_glob = obj_int
+                    self.x = x_int
+                    self.prune()
+            xi = leaf.x[self.data.i_idx]
+            leaf.frac_idx = np.where(abs(xi - np.round(xi)) > self.settings['eps_int_feas'])[0].tolist()
             leaf.constr_idx = self.data.m + dg.nextvar
             leaf.nextvar_idx = self.data.i_idx[dg.nextvar]
             self.add_left(leaf)
@@ -348,9 +360,10 @@ class Workspace(object):
         self.update_lower_glob()
 
     # -- results -------------------------------------------------------------------------
-    def get_return_status(self):
-        # workspace.py:352-373
-        finished = self.iter_num < self.settings['max_iter_bb']
+    def get_return_status(self, finished=None):
+        # workspace.py:352-373; the sharded search passes `finished` (no open leaf on any rank)
+        if finished is None:
+            finished = self.iter_num < self.settings['max_iter_bb']
         if self.upper_glob != np.inf:
             self.status = MI_SOLVED if finished else MI_MAX_ITER_FEASIBLE
         elif self.upper_glob >= 0:

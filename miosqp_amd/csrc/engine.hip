@@ -17,6 +17,9 @@
 // captured once in a hipGraph.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -413,9 +416,18 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         const int rw = 8;
         if (const char *ev = getenv("MIOSQP_COOP_DBG")) d.coop_dbg = atoi(ev);
         const int T = (N + rw - 1) / rw;
-        const bool can = !e->resident && N <= 2048 && T <= prop.multiProcessorCount;
+        bool can = !e->resident && N <= 2048 && T <= prop.multiProcessorCount;
+        if (wantc && can) {
+          // the grid must fit the device with one workgroup per CU: ask the runtime instead of assuming it
+          int per_cu = 0;
+          const hipError_t oq = N <= 1024
+              ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 2>, 512, 0)
+              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 4>, 512, 0);
+          if (oq != hipSuccess || per_cu < 1) can = false;
+        }
         if (wantc && can) {
           e->coop = true;
+          e->coop_capable = true;
           e->coop_rw = rw;
           e->coop_cpt = N <= 1024 ? 2 : 4;
           e->coop_T = T;
@@ -536,10 +548,16 @@ int miosqp_qp_solve(miosqp_qp_engine *e, double *x_out, double *y_out, miosqp_qp
   if (!e || !x_out || !y_out || !info) return MIOSQP_EARG;
   ENTER(e);
   const double t0 = wall();
-  int rc = begin_solve(e);
-  if (!rc) rc = run_loop(e);
-  if (!rc) rc = finish_and_fetch(e, 0, x_out, y_out, info, t0);
-  return rc;
+  maybe_rejoin_coop(e);
+  for (;;) {
+    int rc = begin_solve(e);
+    if (!rc) rc = run_loop(e);
+    if (!rc) rc = finish_and_fetch(e, 0, x_out, y_out, info, t0);
+    if (rc != COOP_RETRY) return rc;
+    // called off before any iterate was touched: the same solve again in the two-kernel form
+    rc = leave_coop(e);
+    if (rc) return rc;
+  }
 }
 
 int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t *i_idx, int32_t m_orig) {
@@ -592,22 +610,16 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, 
   memcpy(e->h_in + M, u, sizeof(double) * M);
   memcpy(e->h_in + 2 * (size_t)M, x0, sizeof(double) * n);
   memcpy(e->h_in + 2 * (size_t)M + n, y0, sizeof(double) * M);
-  for (int attempt = 0;; attempt++) {
+  maybe_rejoin_coop(e);
+  for (;;) {
     HIPCHK(hipEventRecord(e->ev0, e->stream));
     HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * (3 * (size_t)M + n), hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_node_pre, dim3(((M > n ? M : n) + 255) / 256), dim3(256), 0, e->stream, e->d);
     DISPATCH_TPR(e->tpr_pc, k_warm_zw, M, e->stream, e->d);
     int rc = run_loop(e);
     if (!rc) rc = finish_and_fetch(e, 1, x_out, y_out, info, t0);
-    if (rc != MIOSQP_EHIP || !e->coop || !e->coop_timed_out || attempt > 0) return rc;
-    // The cooperative launch could not keep its workgroups co-resident (something else is using the
-    // device).  The node's inputs are still staged, so the node is redone -- and this engine continues --
-    // in the two-kernel product form, which has no such requirement.  Not silent: one line on stderr.
-    fprintf(stderr, "miosqp: %s; this engine continues with the two-kernel form\n", g_err.c_str());
-    e->coop = false;
-    e->coop_timed_out = false;
-    rc = capture_chunk(e, e->chunk, &e->g_full, &e->x_full);
-    if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
+    if (rc != COOP_RETRY) return rc;
+    rc = leave_coop(e);
     if (rc) return rc;
   }
 }
@@ -649,7 +661,22 @@ int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z
       if (rc) return rc;
     }
   } else if (e->coop) {
-    if (k > 0) launch_coop(e, k, 0, 0);
+    if (k > 0) {
+      launch_coop(e, k, 0, 0);
+      HIPCHK(hipMemcpyAsync(e->h_ctrl, e->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (e->h_ctrl->pad == 1) {  // called off, iterates untouched: the same k iterations in the two-kernel form
+        (void)hipMemsetAsync(e->d.coop_reg, 0, 64 * sizeof(unsigned long long), e->stream);
+        g_err = "cooperative solver: the grid was not co-resident within 100 ms (device shared?), stage 1";
+        int rc = leave_coop(e);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, e->d);
+        for (int i = 0; i < k; i++) launch_iteration(e);
+      } else if (e->h_ctrl->pad) {
+        g_err = "cooperative solver: exchange timed out, stage " + std::to_string(e->h_ctrl->pad);
+        return MIOSQP_EHIP;
+      }
+    }
   } else {
     for (int i = 0; i < k; i++) launch_iteration(e);
   }
@@ -668,7 +695,7 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c) 
   return 0;
 }
 
-static void kernel_bytes(const miosqp_qp_engine *e, double b[5]) {
+static void kernel_bytes(const miosqp_qp_engine *e, double b[6]) {
   const double n = e->n, M = e->M, np = (double)e->fa.nnz_panel, nt = (double)e->fa.nnz_tail;
   // 12 B per factor entry (value + index), 4 B row pointers, 8 B vectors
   b[0] = np * 12 + (n + 1) * 4 + (M + 3 * n) * 8;          // panel forward: wh in; x, q in; c out
@@ -677,14 +704,19 @@ static void kernel_bytes(const miosqp_qp_engine *e, double b[5]) {
   b[3] = np * 12 + (M + 1) * 4 + (n + 10 * M) * 8;         // panel backward + z/y update
   const double k = e->st.check_termination;
   const double NK = n + M;
-  b[4] = 2 * (np + nt) * 12 + 2 * (NK + 1) * 4 + NK * 8 + NK * 20 + (6 * n + 16 * M) * 8 +
-         (2.0 * e->nnzA + e->nnzPtriu) * 12 / k;
+  const double rest = 2 * (NK + 1) * 4 + NK * 8 + NK * 20 + (6 * n + 16 * M) * 8 + (2.0 * e->nnzA + e->nnzPtriu) * 12 / k;
+  b[4] = 2 * (np + nt) * 12 + rest;
+  // what the kernels of the form in use REQUEST per iteration: the dense tail (and, in the product form, the
+  // dense G block) carries no index array, so those entries move 8 bytes, not the 12 of the formula above
+  b[5] = (e->fold ? 2 * ((double)n * M + nt) * 8 : 2 * (np * 12 + nt * 8)) + rest;
 }
 
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   if (!e || !out) return MIOSQP_EARG;
-  double b[5];
+  double b[6];
   kernel_bytes(e, b);
+  out[8] = (int64_t)b[5];
+  out[9] = e->coop_fallbacks;
   out[0] = e->fa.nnz_panel + e->fa.nnz_tail;
   out[1] = e->fa.nnz_panel;
   out[2] = e->n;
@@ -811,7 +843,7 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
   HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
   *usec = 1e3 * ms / reps;
   if (bytes) {
-    double b[5];
+    double b[6];
     kernel_bytes(e, b);
     if (which < 10) {
       *bytes = b[which];

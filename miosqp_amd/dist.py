@@ -24,17 +24,23 @@ class LocalComm(object):
     def incumbent(self, value, x):
         return value, 0, x
 
-    def exchange(self, value, x, nleaves, have=None):
-        return value, 0, None, nleaves
+    extra = (0.0, 0.0)  # (nodes, ADMM iterations) summed over the ranks at the last completed exchange
 
-    def post(self, value, x, nleaves):
-        return (value, nleaves)
+    def exchange(self, value, x, nleaves, have=None, extra=(0.0, 0.0)):
+        return self.complete(self.post(value, x, nleaves, extra), have)
+
+    def post(self, value, x, nleaves, extra=(0.0, 0.0)):
+        return (value, nleaves, extra)
 
     def complete(self, h, have=None):
+        self.extra = tuple(h[2])
         return h[0], 0, None, h[1]
 
     def leaf_counts(self):
         return None
+
+    def gather(self, vec):
+        return np.asarray(vec, dtype=np.float64).reshape(1, -1)
 
     def move(self, arr, size, src):
         raise RuntimeError("single rank")
@@ -54,15 +60,17 @@ class TorchComm(object):
         import torch.distributed as dist
         self.torch, self.dist, self.device = torch, dist, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.extra = (0.0, 0.0)
         self.n_hint = 0  # length of x for ranks that hold no incumbent yet (set by ShardedSearch)
 
-    def post(self, value, x, nleaves):
-        """First half of exchange(): the all-gather of (incumbent value, open-leaf count) is enqueued
-        (async_op) and nothing is waited for; returns the handle for complete().  The incumbent x is
-        snapshotted so that a later broadcast sends the point that belongs to `value`."""
+    def post(self, value, x, nleaves, extra=(0.0, 0.0)):
+        """First half of exchange(): the all-gather of (incumbent value, open-leaf count, nodes and ADMM
+        iterations of this step) is enqueued (async_op) and nothing is waited for; returns the handle for
+        complete().  The incumbent x is snapshotted so that a later broadcast sends the point that belongs
+        to `value`."""
         t = self.torch
-        mine = t.tensor([value, float(nleaves)], dtype=t.float64, device=self.device)
-        allv = t.empty(2 * self.world, dtype=t.float64, device=self.device)
+        mine = t.tensor([value, float(nleaves), float(extra[0]), float(extra[1])], dtype=t.float64, device=self.device)
+        allv = t.empty(4 * self.world, dtype=t.float64, device=self.device)
         work = self.dist.all_gather_into_tensor(allv, mine, async_op=True)
         return (work, allv, mine, None if x is None else np.array(x, dtype=np.float64, copy=True))
 
@@ -73,8 +81,9 @@ class TorchComm(object):
         t = self.torch
         work, allv, _mine, xsnap = h
         work.wait()
-        tab = allv.cpu().numpy().reshape(self.world, 2)
+        tab = allv.cpu().numpy().reshape(self.world, 4)
         self._counts = [int(round(c)) for c in tab[:, 1]]
+        self.extra = (float(tab[:, 2].sum()), float(tab[:, 3].sum()))
         owner = int(np.argmin(tab[:, 0]))
         best = float(tab[owner, 0])
         total = int(round(tab[:, 1].sum()))
@@ -88,9 +97,17 @@ class TorchComm(object):
         self.dist.broadcast(buf, src=owner)
         return best, owner, buf.cpu().numpy(), total
 
-    def exchange(self, value, x, nleaves, have=None):
+    def exchange(self, value, x, nleaves, have=None, extra=(0.0, 0.0)):
         """Blocking exchange: post() + complete()."""
-        return self.complete(self.post(value, x, nleaves), have)
+        return self.complete(self.post(value, x, nleaves, extra), have)
+
+    def gather(self, vec):
+        """Blocking all-gather of a short float vector: array [world, len(vec)]."""
+        t = self.torch
+        mine = t.tensor(np.asarray(vec, dtype=np.float64), dtype=t.float64, device=self.device)
+        allv = t.empty(self.world * mine.numel(), dtype=t.float64, device=self.device)
+        self.dist.all_gather_into_tensor(allv, mine)
+        return allv.cpu().numpy().reshape(self.world, -1)
 
     def incumbent(self, value, x):
         best, owner, xb, _ = self.exchange(value, x, 0)
@@ -153,6 +170,15 @@ class ShardedSearch(object):
         if hasattr(self.comm, "n_hint"):
             self.comm.n_hint = self.work.data.n
         self.moved = 0
+        self.resyncs = 0          # times the replicated phase had to adopt rank 0's leaves (see _agree)
+        self.global_nodes = 0     # nodes visited by all ranks together (replicated work counted once)
+        self.global_iters = 0
+        self.global_open = 1      # open leaves over all ranks as of the last exchange
+        self._step_nodes = 0      # this rank's nodes / iterations since its last post()
+        self._step_iters = 0
+        # MIOSQP_FORCE_EXCHANGE=1: run the collectives even with one rank (a 1-GPU torchrun launch then
+        # exercises the RCCL path end to end; results are unchanged)
+        self.force_exchange = os.environ.get("MIOSQP_FORCE_EXCHANGE") == "1"
         self.feed = int(os.environ.get("MIOSQP_FEED", "1"))  # leaves handed to a dry rank per exchange
         # which leaf a donor hands over: its oldest (shallowest: the largest subtree, keeps the receiver busy
         # longest; simulated +0.02 efficiency at 8 ranks) or its newest (MIOSQP_DONATE=last)
@@ -165,11 +191,73 @@ class ShardedSearch(object):
         self.drain(apply=False)
         self.replicated = True
         self.global_upper = np.inf
+        self.global_nodes = self.global_iters = 0
+        self.global_open = 1
+        self._step_nodes = self._step_iters = 0
 
     def _count(self, leaf):
         if not self.replicated or self.comm.rank == 0:
             self.nodes += 1
             self.iters += leaf.num_iter
+        if self.replicated or self.comm.world == 1:
+            self.global_nodes += 1  # the same node on every rank: counted once, no exchange needed
+            self.global_iters += leaf.num_iter
+        else:
+            self._step_nodes += 1   # summed over the ranks by the next exchange
+            self._step_iters += leaf.num_iter
+
+    # -- replicated phase: the ranks must hold the SAME leaves before they deal them ---------------
+    @staticmethod
+    def _fingerprint(leaves):
+        """Order-sensitive checksum of the open leaves' bounds (what identifies a leaf), < 2^48 so that it
+        survives the float64 all-gather exactly."""
+        import hashlib
+        h = hashlib.blake2b(digest_size=6)
+        for lf in leaves:
+            h.update(np.ascontiguousarray(lf.l, dtype=np.float64).tobytes())
+            h.update(np.ascontiguousarray(lf.u, dtype=np.float64).tobytes())
+            h.update(np.int64(lf.depth).tobytes())
+        return float(int.from_bytes(h.digest(), "little"))
+
+    def _leaf_record(self, lf):
+        return np.concatenate([lf.l, lf.u, lf.x, lf.y, [float(lf.depth), float(lf.lower), 1.0]])
+
+    def _leaf_from_record(self, msg):
+        from miosqp_amd.bnb import Node
+        w = self.work
+        n, M = w.data.n, w.data.m + w.data.n_int
+        return Node(w.data, msg[:M].copy(), msg[M:2 * M].copy(), w.solver, depth=int(msg[-3]), lower=float(msg[-2]),
+                    x0=msg[2 * M:2 * M + n].copy(), y0=msg[2 * M + n:3 * M + n].copy(), constant=w.constant)
+
+    def _agree(self):
+        """While replicated every rank visits the same nodes and is ASSUMED to get the same results; nothing
+        guarantees it (a rank whose cooperative launch was called off continues in the two-kernel form, whose
+        summation order differs: one more or one fewer test, another branching variable).  So after every
+        replicated node the ranks compare (open leaves, checksum of their bounds, incumbent) in one
+        all-gather; on any difference everybody adopts rank 0's leaves and incumbent (broadcast records).
+        Afterwards the leaf lists are identical, so `deal()` partitions one list and every rank takes the
+        same decision about dealing and about the tree being closed."""
+        w, comm = self.work, self.comm
+        if comm.world == 1 and not self.force_exchange:
+            return
+        ug = w.upper_glob if np.isfinite(w.upper_glob) else 1e300
+        tab = comm.gather([float(len(w.leaves)), self._fingerprint(w.leaves), ug])
+        if np.all(tab == tab[0]):
+            return
+        self.resyncs += 1
+        n, M = w.data.n, w.data.m + w.data.n_int
+        size = 3 * M + n + 3
+        count = int(tab[0][0])
+        mine = w.leaves
+        adopted = []
+        for k in range(count):
+            msg = comm.move(self._leaf_record(mine[k]) if comm.rank == 0 else None, size, 0)
+            adopted.append(mine[k] if comm.rank == 0 else self._leaf_from_record(msg))
+        w.leaves = adopted
+        inc = comm.move(np.concatenate([[w.upper_glob], w.x]) if comm.rank == 0 else None, n + 1, 0)
+        if comm.rank != 0:
+            w.upper_glob = float(inc[0])
+            w.x = inc[1:].copy()
 
     def deal(self):
         """Round-robin partition of the open leaves; rank r keeps leaves r, r+W, r+2W, ..."""
@@ -273,12 +361,13 @@ class ShardedSearch(object):
         if not (batched and pipelined):
             self.flush_wave()  # the engine is used from this thread below
         if self.replicated:
-            if len(w.leaves) >= self.comm.world or not w.leaves:
-                if w.leaves:
-                    self.deal()
-            else:
-                self._visit(rule)  # same node on every rank; nothing to exchange
-                return max(1, len(w.leaves)) if w.leaves else 0
+            if w.leaves and len(w.leaves) < self.comm.world:
+                self._visit(rule)  # same node on every rank ...
+                self._agree()      # ... checked: identical leaf lists from here on
+                self.global_open = len(w.leaves)
+                return len(w.leaves)
+            if w.leaves:
+                self.deal()
         if batched:
             self._visit_wave(rule, nodes_per_rank, pipelined)
         elif budget:
@@ -303,9 +392,11 @@ class ShardedSearch(object):
         the one of the previous step; the returned total is then one step old (and 1 when nothing is
         known yet)."""
         w = self.work
-        if self.comm.world == 1:
-            return self._open()
-        h = self.comm.post(w.upper_glob, w.x, self._open())
+        if self.comm.world == 1 and not self.force_exchange:
+            self.global_open = self._open()
+            return self.global_open
+        h = self.comm.post(w.upper_glob, w.x, self._open(), (self._step_nodes, self._step_iters))
+        self._step_nodes = self._step_iters = 0
         if self.lag == 0:
             return self._apply(h)
         prev, self._pending = self._pending, h
@@ -316,6 +407,10 @@ class ShardedSearch(object):
     def _apply(self, h):
         w = self.work
         best, owner, x, total = self.comm.complete(h, self.global_upper)
+        if self.comm.world > 1:
+            self.global_nodes += int(round(self.comm.extra[0]))
+            self.global_iters += int(round(self.comm.extra[1]))
+        self.global_open = total
         if x is not None:
             self.global_upper = best
             if best < w.upper_glob:
@@ -360,18 +455,13 @@ class ShardedSearch(object):
             if me == donor:
                 if len(w.leaves) >= 2:
                     lf = w.leaves.pop(0) if self.donate_first else w.leaves.pop()
-                    msg = np.concatenate([lf.l, lf.u, lf.x, lf.y, [float(lf.depth), float(lf.lower), 1.0]])
+                    msg = self._leaf_record(lf)
                     self.moved += 1
                 else:  # pruned in the meantime: an empty token keeps the collective matched
                     msg = np.zeros(size)
             msg = self.comm.move(msg, size, donor)
-            if me == recv:
-                if msg[-1] == 1.0:
-                    from miosqp_amd.bnb import Node
-                    w.leaves.append(Node(w.data, msg[:M].copy(), msg[M:2 * M].copy(), w.solver,
-                                         depth=int(msg[-3]), lower=float(msg[-2]),
-                                         x0=msg[2 * M:2 * M + n].copy(), y0=msg[2 * M + n:3 * M + n].copy(),
-                                         constant=w.constant))
+            if me == recv and msg[-1] == 1.0:
+                w.leaves.append(self._leaf_from_record(msg))
 
     def open_leaves(self):
         return int(self.comm.sum([len(self.work.leaves)])[0])
@@ -380,12 +470,19 @@ class ShardedSearch(object):
         """Waves until no rank has leaves left (or max_waves)."""
         waves = 0
         total = 1
-        while waves < max_waves and total > 0:
+        cap = self.work.settings['max_iter_bb']
+        # the reference visits at most max_iter_bb - 1 nodes (workspace.py:113-126: iter_num starts at 1); here
+        # the budget is global -- nodes of all ranks together, known to every rank from the exchange -- so
+        # every rank stops after the same step (ranks overshoot by at most one step's nodes)
+        while waves < max_waves and total > 0 and self.global_nodes + 1 < cap:
             total = self.step(nodes_per_rank, batched, pipelined)
             waves += 1
         self.flush_wave()
         self.drain()
         w = self.work
-        w.get_return_status()
+        # rank-uniform status: "finished" is a property of the whole tree (no open leaf on any rank), not of
+        # this rank's own node count
+        w.osqp_iter_avg = self.global_iters / float(max(1, self.global_nodes + 1))
+        w.get_return_status(finished=(self.global_open == 0 and self._open() == 0))
         w.get_return_solution()
         return waves

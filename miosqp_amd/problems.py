@@ -60,3 +60,46 @@ def extended(prob):
     I = spa.identity(n, format="csc")[prob["i_idx"], :]
     A_ext = spa.vstack([A, I]).tocsc()
     return A_ext, np.append(prob["l"], prob["i_l"]), np.append(prob["u"], prob["i_u"])
+
+
+def load_power_converter(path=None):
+    """BASELINE configs[3]: the power-converter MPC sequence, horizon N=3 (n=18, 45 rows), as recorded from
+    the reference's closed-loop simulation (/root/reference/examples/power_converter/power_converter.py:
+    421-508, 589-675) by tests/golden/make_power_converter.py -- data only: the MIQP matrices, and per MPC
+    step the vectors passed to MIOSQP.update_vectors, the warm start passed to set_x0 and what the
+    reference's tree search returned."""
+    import json
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                            "power_converter_N3.npz")
+    z = np.load(path, allow_pickle=False)
+    P = spa.csc_matrix((z["P_data"], z["P_indices"], z["P_indptr"]), shape=tuple(z["P_shape"]))
+    A = spa.csc_matrix((z["A_data"], z["A_indices"], z["A_indptr"]), shape=tuple(z["A_shape"]))
+    return dict(P=P, A=A, l=z["l"].copy(), i_idx=z["i_idx"].copy(), i_l=z["i_l"].copy(), i_u=z["i_u"].copy(),
+                settings=json.loads(str(z["settings"])), qp_settings=json.loads(str(z["qp_settings"])),
+                q=z["q"], u=z["u"], x0=z["x0"], x=z["x"], upper=z["upper"], status=[str(s) for s in z["status"]],
+                nodes=z["nodes"], osqp_iter=z["osqp_iter"])
+
+
+def run_power_converter(pc, backend, steps=None, model=None):
+    """Replays the MPC sequence exactly as the reference's compute_mpc_input drives MIOSQP
+    (/root/reference/examples/power_converter/power_converter.py:467-476): setup once, then per step
+    update_vectors(q, l, u) + set_x0(shifted previous solution) + solve.  Returns (per-step records, model)."""
+    from miosqp_amd import bnb
+    steps = len(pc["q"]) if steps is None else steps
+    out = []
+    l = pc["l"].copy()
+    for k in range(steps):
+        q, u = pc["q"][k].copy(), pc["u"][k].copy()
+        if model is None:
+            model = bnb.MIOSQP(backend=backend)
+            model.setup(pc["P"], q, pc["A"], l, u, pc["i_idx"], pc["i_l"], pc["i_u"], pc["settings"],
+                        pc["qp_settings"])
+        else:
+            model.update_vectors(q, l, u)
+        model.set_x0(pc["x0"][k].copy())
+        res = model.solve()
+        out.append(dict(x=np.array(res.x, dtype=float), upper=res.upper_glob, status=res.status,
+                        nodes=model.work.iter_num - 1, osqp_iter=model.work.osqp_iter))
+    return out, model

@@ -204,11 +204,12 @@ class OSQP(object):
         return D, E, c.value
 
     def factor_stats(self):
-        out = np.zeros(8, dtype=np.int64)
+        out = np.zeros(10, dtype=np.int64)
         _check(self._lib.miosqp_qp_get_factor_stats(self._h, out.ctypes.data_as(_lib.i64p)),
                "get_factor_stats")
         return dict(nnz_L=int(out[0]), nnz_panel=int(out[1]), tail_order=int(out[2]),
-                    bytes_per_iter=int(out[3]), tpr=(int(out[4]), int(out[5]), int(out[6])),
+                    bytes_per_iter=int(out[3]), bytes_moved_per_iter=int(out[8]), coop_fallbacks=int(out[9]),
+                    tpr=(int(out[4]), int(out[5]), int(out[6])),
                     fold=bool(out[7] & 1), resident=bool(out[7] & 2), setup_on_device=bool(out[7] & 4), coop=bool(out[7] & 8), coop_nap=(out[7] >> 8) & 0xff)
 
     def loop_stats(self, reset=False):

@@ -92,3 +92,81 @@ def test_time_budgeted_steps_reach_the_same_optimum(budget):
         assert abs(up - r.upper_glob) <= 1e-3 * max(1.0, abs(r.upper_glob))
         # the same integer assignment, to the integrality tolerance (which node delivers the incumbent differs)
         np.testing.assert_allclose(x[pr["i_idx"]], r.x[pr["i_idx"]], atol=1e-3, rtol=0)
+
+
+def _threads(world, body):
+    tw = ThreadWorld(world)
+    out, err = [None] * world, []
+
+    def main(rank):
+        try:
+            out[rank] = body(rank, ThreadComm(tw, rank))
+        except Exception as e:
+            err.append(e)
+            tw.bar.abort()
+
+    th = [threading.Thread(target=main, args=(k,)) for k in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not err, err
+    return out
+
+
+def test_replicated_phase_survives_a_rank_that_disagrees():
+    """one rank's relaxations differ slightly during the replicated ramp-up (as after a cooperative
+    launch was called off on that GPU).  Rank 2 is made to lose a leaf after its first replicated node: the
+    all-gather of (count, checksum, incumbent) notices, everybody adopts rank 0's leaves, the deal partitions ONE
+    list, no collective is left unmatched and the optimum is the sequential one."""
+    pr = problems.random_miqp(30, 150, 15, seed=4)
+    ref = bnb.MIOSQP(backend=digest_backend)
+    ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+              dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    r = ref.solve()
+
+    def body(rank, comm):
+        m = bnb.MIOSQP(backend=digest_backend)
+        m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+        s = dist.ShardedSearch(m, comm)
+        if rank == 2:
+            real, state = s._visit, dict(done=False)
+
+            def bad_visit(rule):
+                leaf = real(rule)
+                if s.replicated and not state["done"] and len(m.work.leaves) >= 2:
+                    m.work.leaves.pop()  # this rank now disagrees with the others
+                    state["done"] = True
+                return leaf
+            s._visit = bad_visit
+        s.run(nodes_per_rank=1)
+        return dict(upper=m.work.upper_glob, x=np.array(m.work.x), status=m.work.status, resyncs=s.resyncs,
+                    leaves=len(m.work.leaves), gnodes=s.global_nodes, nodes=s.nodes)
+
+    out = _threads(4, body)
+    assert all(o["resyncs"] == 1 for o in out)
+    for o in out:
+        assert o["status"] == bnb.MI_SOLVED and o["leaves"] == 0 and o["upper"] == out[0]["upper"]
+        assert abs(o["upper"] - r.upper_glob) <= 1e-3 * max(1.0, abs(r.upper_glob))
+        np.testing.assert_array_equal(o["x"][pr["i_idx"]], r.x[pr["i_idx"]])
+        assert o["gnodes"] == out[0]["gnodes"] == sum(q["nodes"] for q in out)  # every rank knows the global count
+
+
+def test_global_node_budget_and_uniform_status():
+    """max_iter_bb is a budget on the nodes of ALL ranks together, every rank stops after the same step
+    and reports the same status (the reference's rule, workspace.py:352-373, applied to the whole tree)."""
+    pr = problems.random_miqp(30, 150, 15, seed=4)
+
+    def body(rank, comm):
+        st = dict(problems.BNB_SETTINGS, max_iter_bb=12)
+        m = bnb.MIOSQP(backend=digest_backend)
+        m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
+                dict(problems.QP_SETTINGS))
+        s = dist.ShardedSearch(m, comm)
+        waves = s.run(nodes_per_rank=1)
+        return dict(status=m.work.status, gnodes=s.global_nodes, waves=waves, avg=m.work.osqp_iter_avg)
+
+    out = _threads(4, body)
+    assert len(set(o["status"] for o in out)) == 1 and len(set(o["waves"] for o in out)) == 1
+    assert out[0]["status"] in (bnb.MI_MAX_ITER_FEASIBLE, bnb.MI_MAX_ITER_UNSOLVED)
+    assert 11 <= out[0]["gnodes"] <= 11 + 4  # stops once the budget is reached; overshoot < one step of 4 ranks
+    assert out[0]["avg"] > 0 and len(set(o["avg"] for o in out)) == 1

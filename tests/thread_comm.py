@@ -29,13 +29,18 @@ class ThreadComm(object):
         tw.bar.wait()
         return out
 
-    def post(self, value, x, nleaves):
+    extra = (0.0, 0.0)
+
+    def gather(self, vec):
+        return np.array(self._all(np.asarray(vec, dtype=np.float64)))
+
+    def post(self, value, x, nleaves, extra=(0.0, 0.0)):
         """Non-blocking half: deposit this rank's entry of exchange number k."""
         tw = self.tw
         k = self._posted
         self._posted += 1
         with tw.cv:
-            tw.rounds.setdefault(k, [None] * self.world)[self.rank] = (value, nleaves, None if x is None else np.array(x))
+            tw.rounds.setdefault(k, [None] * self.world)[self.rank] = (value, nleaves, None if x is None else np.array(x), tuple(extra))
             tw.cv.notify_all()
         return k
 
@@ -47,11 +52,12 @@ class ThreadComm(object):
             tab = list(tw.rounds[k])
         return self._decide(tab, have)
 
-    def exchange(self, value, x, nleaves, have=None):
-        return self.complete(self.post(value, x, nleaves), have)
+    def exchange(self, value, x, nleaves, have=None, extra=(0.0, 0.0)):
+        return self.complete(self.post(value, x, nleaves, extra), have)
 
     def _decide(self, tab, have):
         self._counts = [int(t[1]) for t in tab]
+        self.extra = (float(sum(t[3][0] for t in tab)), float(sum(t[3][1] for t in tab)))
         vals = np.array([t[0] for t in tab])
         owner = int(np.argmin(vals))
         best = float(vals[owner])

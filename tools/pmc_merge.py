@@ -21,7 +21,7 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, {}).get("FETCH_SIZE")
         w = write.get(k, {}).get("WRITE_SIZE")
-        rec = {"dispatches": (f or w)["dispatches"]}
+        rec = {"dispatches": (f or w)["dispatches"], "early_exit_dispatches": (f or w).get("early_exit_dispatches", 0)}
         if f:
             rec["FETCH_SIZE_KiB"] = round(f["mean"], 3)
         if w:
