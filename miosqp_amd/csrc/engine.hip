@@ -138,6 +138,7 @@ struct Dev {
   double *b_xfin, *b_yfin;  // unscaled answers, batch-fastest
   double *b_xi, *b_xis;     // rounded candidates (node digest), unscaled / scaled
   double *b_part;           // partial reductions of the batched termination test
+  const double *b_zero;     // a page of zeros (matrix-core tiles: operand of a chunk beyond the end)
   int *c_intinf, *c_nextvar;
   int *c_node;   // column position -> node of the wave (columns are swapped when the wave is compacted)
   int *c_pairs;  // swap list of the current compaction
@@ -458,6 +459,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         }
       }
       if (const char *ev = getenv("MIOSQP_BD_CFG")) e->bd_cfg = atoi(ev);
+      if (const char *ev = getenv("MIOSQP_BM_VAR")) e->bm_var = atoi(ev);
       if (const char *ev = getenv("MIOSQP_SPIN_WAIT")) e->spin_wait = atoi(ev) != 0;
       if (const char *ev = getenv("MIOSQP_COMPACT")) e->compact = atoi(ev) != 0;
       if (const char *ev = getenv("MIOSQP_BM_ABLATE")) d.bm_ablate = atoi(ev);
@@ -740,17 +742,25 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 // debug: per-block (start, end) wall-clock stamps (100 MHz) of ONE launch of a product-form kernel
 int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
                              int32_t *nblocks) {
-  if (!e || !out || !e->fold || which < 0 || which > 2 || (which == 2 && !e->coop)) return MIOSQP_EARG;
+  if (!e || !out || !e->fold || which < 0 || which > 3 || (which == 2 && !e->coop) || (which >= 3 && e->Bcap == 0))
+    return MIOSQP_EARG;
   ENTER(e);
   unsigned long long *buf = nullptr;
   HIPCHK(hipMalloc((void **)&buf, sizeof(unsigned long long) * 2 * 8192));
   HIPCHK(hipMemsetAsync(buf, 0, sizeof(unsigned long long) * 2 * 8192, e->stream));
-  for (int i = 0; i < 20; i++) launch_iteration(e);
+  if (which >= 3) {
+    for (int i = 0; i < 5; i++) launch_iteration_b(e, e->Bcap / 64);
+  } else {
+    for (int i = 0; i < 20; i++) launch_iteration(e);
+  }
   Dev saved = e->d;
   e->d.prof = buf;
   // which == 2: 1000 iterations of the cooperative solver; per workgroup 8 words: shader clocks of
   // thread 0 in {reduce, update+publish, gather}, iterations, {test operands+rows, test norms}, tests, -
-  if (which == 2) launch_coop(e, 1000, 25, 0);
+  // which == 3: the batched forward sweep (kbm_fwd) at full width; per workgroup 8 words (100 MHz stamps of wave 0):
+  // start, first loads issued, first operands arrived, sweep done, reduced, stored
+  if (which == 3) launch_bd(e, e->Bcap / 64, 0);
+  else if (which == 2) launch_coop(e, 1000, 25, 0);
   else if (which == 0) launch_fold_fwd(e); else launch_fold_bwd(e);
   e->d = saved;
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -223,7 +223,7 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
   f.M = M;
   f.rho = rho;
   f.sigma = sigma;
-  f.ld = (n + 7) & ~7;
+  f.ld = (n + 15) & ~15;  // multiples of 16: the batched matrix-core tiles read whole 16-deep chunks of a row
   const int ld = f.ld;
 
   // ---- panel: rows of Abar^T (per variable) and rows of Abar (per constraint) ----------
@@ -422,8 +422,8 @@ void build_folded(const Factor &f, Folded &o) {
   const int n = f.n, M = f.M, ld = f.ld;
   o.n = n;
   o.M = M;
-  o.ldf = (M + n + 7) & ~7;
-  o.ldn = (n + 7) & ~7;
+  o.ldf = (M + n + 15) & ~15;
+  o.ldn = (n + 15) & ~15;
   o.rows.assign((size_t)n * o.ldf, 0.0);
   o.GmT.assign((size_t)(M > 0 ? M : 1) * o.ldn, 0.0);
   const PCsr &R = f.panel_by_var;  // rows of L21
@@ -443,7 +443,7 @@ void build_folded(const Factor &f, Folded &o) {
   for (int i = 0; i < n; i++)
     for (int j = 0; j < M; j++) o.GmT[(size_t)j * o.ldn + i] = o.rows[(size_t)i * o.ldf + j];
   // dense Abar, Abar^T, Pbar
-  o.ldm = (M + 7) & ~7;
+  o.ldm = (M + 15) & ~15;
   o.Ad.assign((size_t)(M > 0 ? M : 1) * o.ldn, 0.0);
   o.Atd.assign((size_t)n * o.ldm, 0.0);
   o.Pd.assign((size_t)n * o.ldn, 0.0);
