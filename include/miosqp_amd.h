@@ -147,6 +147,53 @@ int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const
                           const double *x0, const double *y0, double *x_out, double *y_out,
                           miosqp_qp_info *info);
 
+/* ---- device-resident leaf pool + streaming batch -------------------------------------------------------
+ * Workspace.leaves and child generation (/root/reference/miosqp/workspace.py:83,
+ * 157-203) kept on the device.  A node = its integer-row bounds (rows m .. M-1; workspace.py:227) + a warm
+ * start = the solution of its parent's slot (workspace.py:174-176, 198-200).  The host owns slot numbers and
+ * the search logic (choose_leaf / prune / incumbent: workspace.py:128-155, 274-334) on 64-byte digests; the
+ * only vectors that cross PCIe are an incumbent's x when one is found.  The batch's columns are refilled
+ * from a ready ring between chunks (check_termination iterations + one test), so a finished node's column
+ * does not wait for the slowest node of a wave; every node still gets exactly the iterations and tests
+ * miosqp_qp_solve_node would give it.  Needs set_integer_rows + set_root, and max_iter % check_termination == 0. */
+typedef struct miosqp_pool_digest {
+  int32_t slot;        /* pool slot of the node */
+  int32_t status_val;  /* as miosqp_qp_info.status_val; -100 = dropped at refill: its bound exceeded the incumbent */
+  int32_t iter;
+  int32_t int_inf;     /* -1 when the relaxation was infeasible */
+  int32_t nextvar;     /* branching variable (position in i_idx); the children were written when int_inf > 0 */
+  int32_t reserved;
+  double lower;        /* objective at the clamped x (node.py:143); NaN when infeasible */
+  double heur_viol;    /* <= 0: the rounded candidate satisfies the root constraints */
+  double heur_obj;
+  double pri_res, dua_res;
+} miosqp_pool_digest;
+
+/* capacity: node slots; columns: width of the streaming batch (<= 1024, rounded up to 64) */
+int miosqp_qp_pool_create(miosqp_qp_engine *e, int32_t capacity, int32_t columns);
+/* empties columns, ready ring and digests (new MIQP on the same factor: after update_vectors / set_root) */
+int miosqp_qp_pool_reset(miosqp_qp_engine *e);
+/* a node given by the host (root, or a leaf received from another rank): integer-row bounds (n_int each) and an
+ * explicit warm start x0 (n), y0 (M) */
+int miosqp_qp_pool_write_node(miosqp_qp_engine *e, int32_t slot, const double *l_int, const double *u_int,
+                              const double *x0, const double *y0);
+/* integer-row bounds and, for a solved node, its solution (any pointer may be NULL) */
+int miosqp_qp_pool_read_node(miosqp_qp_engine *e, int32_t slot, double *l_int, double *u_int, double *x, double *y);
+/* appends nodes to the ready ring in the order they should be solved: slot, the two slots its children are to be
+ * written into (-1: none), and the bound it inherited (dropped unsolved once that exceeds the incumbent) */
+int miosqp_qp_pool_push(miosqp_qp_engine *e, int32_t count, const int32_t *slot, const int32_t *child0,
+                        const int32_t *child1, const double *lower);
+/* incumbent value for the refill-time bound test */
+int miosqp_qp_pool_set_upper(miosqp_qp_engine *e, double upper);
+/* enqueues `chunks` x (refill, check_termination iterations, test, harvest) and returns at once */
+int miosqp_qp_pool_launch(miosqp_qp_engine *e, int32_t chunks);
+/* waits until at most `keep_in_flight` launches are still running (oldest first: with 1 the device works on the
+ * newest launch while the host handles the results of the one before); digests of the nodes decided (or dropped)
+ * since the last call, at most max_out; *active = columns holding a node after the last refill seen,
+ * *ready_left = ready-ring entries not yet taken */
+int miosqp_qp_pool_collect(miosqp_qp_engine *e, int32_t keep_in_flight, miosqp_pool_digest *out, int32_t max_out,
+                           int32_t *n_out, int32_t *active, int64_t *ready_left);
+
 /* frees device and host memory */
 int miosqp_qp_cleanup(miosqp_qp_engine *e);
 

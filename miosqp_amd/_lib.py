@@ -30,6 +30,12 @@ class Info(C.Structure):
                 ("heur_obj", C.c_double)]
 
 
+class PoolDigest(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("status_val", C.c_int32), ("iter", C.c_int32), ("int_inf", C.c_int32),
+                ("nextvar", C.c_int32), ("reserved", C.c_int32), ("lower", C.c_double), ("heur_viol", C.c_double),
+                ("heur_obj", C.c_double), ("pri_res", C.c_double), ("dua_res", C.c_double)]
+
+
 # every symbol include/miosqp_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "miosqp_qp_default_settings": (C.c_int, [C.POINTER(Settings)]),
@@ -45,6 +51,15 @@ SYMBOLS = {
     "miosqp_qp_solve_node": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, C.POINTER(Info)]),
     "miosqp_qp_solve_batch": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp,
                                         C.POINTER(Info)]),
+    "miosqp_qp_pool_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "miosqp_qp_pool_reset": (C.c_int, [C.c_void_p]),
+    "miosqp_qp_pool_write_node": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp]),
+    "miosqp_qp_pool_read_node": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp]),
+    "miosqp_qp_pool_push": (C.c_int, [C.c_void_p, C.c_int32, ip, ip, ip, dp]),
+    "miosqp_qp_pool_set_upper": (C.c_int, [C.c_void_p, C.c_double]),
+    "miosqp_qp_pool_launch": (C.c_int, [C.c_void_p, C.c_int32]),
+    "miosqp_qp_pool_collect": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PoolDigest), C.c_int32, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), i64p]),
     "miosqp_qp_cleanup": (C.c_int, [C.c_void_p]),
     "miosqp_qp_last_error": (C.c_char_p, []),
     "miosqp_qp_debug_iterate": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp]),

@@ -82,6 +82,9 @@ struct Ctrl {
   double heur_viol, heur_obj;
 };
 
+struct PoolCtl;
+struct ReadyEntry;
+
 // everything a kernel needs, passed by value
 struct Dev {
   int n, M, ld, n_int, m_orig;
@@ -139,6 +142,20 @@ struct Dev {
   double *b_xi, *b_xis;     // rounded candidates (node digest), unscaled / scaled
   double *b_part;           // partial reductions of the batched termination test
   const double *b_zero;     // a page of zeros (matrix-core tiles: operand of a chunk beyond the end)
+  // ---- leaf pool + streaming batch (kernels_pool.inc) ----
+  int stream;               // 1: columns are refilled from the pool between chunks and count their own iterations
+  int max_iter_s, ring;
+  int *c_start, *c_child0, *c_child1, *c_harv, *t_has;
+  int *fmap, *hmap;         // columns refilled / harvested in the current chunk
+  double *lt_x;             // load tile: scaled x of the refilled columns, [n][64]
+  const int *int_pos;       // variable -> its position in i_idx, or -1
+  double *pl_lo, *pl_hi;    // [cap][n_int] integer-row bounds of every node
+  int *pl_ws;               // slot whose solution is the node's warm start
+  double *sol_x, *sol_y;    // [cap][n], [cap][M] solutions of solved nodes (x clamped as node.py:131-136)
+  PoolCtl *pctl;            // device-side counters
+  PoolCtl *hctl;            // host memory: [0] host -> device (tail, upper), [1] device -> host (head, fin, active)
+  ReadyEntry *ready;        // host memory: ready ring
+  miosqp_pool_digest *dg_ring;  // host memory: digests of decided nodes
   int *c_intinf, *c_nextvar;
   int *c_node;   // column position -> node of the wave (columns are swapped when the wave is compacted)
   int *c_pairs;  // swap list of the current compaction
@@ -158,7 +175,9 @@ struct Dev {
 #include "kernels_resident.inc"  // LDS-resident single-workgroup solver (k_resident)
 #include "kernels_node.inc"  // per-solve prologue / epilogue kernels (scaling, warm start, finish, node digest, objective)
 #include "kernels_batched.inc"  // batched mode: sparse row kernels, dense vector-FMA tiles, fp64 matrix-core tiles, batched test
+#include "kernels_pool.inc"  // device-resident leaf pool, streaming batch (refill / harvest between chunks)
 #include "host.inc"  // host side: engine object, allocation, launches, graph capture, solve loops
+#include "host_pool.inc"  // host side of the leaf pool (C ABI miosqp_qp_pool_*)
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -215,6 +234,12 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->h_ctrl2) hipHostFree(e->h_ctrl2);
   if (e->ev_chunk[0]) hipEventDestroy(e->ev_chunk[0]);
   if (e->ev_chunk[1]) hipEventDestroy(e->ev_chunk[1]);
+  drop_stream_graph(e);
+  for (hipEvent_t ev : e->ev_pool)
+    if (ev) hipEventDestroy(ev);
+  if (e->h_ready) hipHostFree(e->h_ready);
+  if (e->h_dg) hipHostFree(e->h_dg);
+  if (e->h_pctl) hipHostFree(e->h_pctl);
   if (e->hb_in) hipHostFree(e->hb_in);
   if (e->hb_out) hipHostFree(e->hb_out);
   if (e->hb_int) hipHostFree(e->hb_int);
@@ -571,6 +596,17 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
   for (int k = 0; k < n_int; k++)
     if (i_idx[k] < 0 || i_idx[k] >= e->n) return MIOSQP_EARG;
   if (n_int) HIPCHK(hipMemcpy((void *)e->d.i_idx, i_idx, sizeof(int) * n_int, hipMemcpyHostToDevice));
+  {
+    std::vector<int> pos(e->n, -1);
+    for (int k = 0; k < n_int; k++) pos[i_idx[k]] = k;
+    if (!e->d.int_pos) {
+      int *ip = nullptr;
+      int rc = dalloc(e, &ip, (size_t)e->n);
+      if (rc) return rc;
+      e->d.int_pos = ip;
+    }
+    HIPCHK(hipMemcpy((void *)e->d.int_pos, pos.data(), sizeof(int) * e->n, hipMemcpyHostToDevice));
+  }
   e->d.n_int = n_int;
   e->d.m_orig = m_orig;
   e->have_int = true;
@@ -590,9 +626,13 @@ int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *
     HIPCHK(hipMemcpy(e->d.root_l, l_root, sizeof(double) * e->M, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d.root_u, u_root, sizeof(double) * e->M, hipMemcpyHostToDevice));
   }
+  if (e->x_stream && (e->d.eps_int != eps_int_feas || e->d.eps_lin != eps_lin)) drop_stream_graph(e);  // captured by value
   e->d.eps_int = eps_int_feas;
   e->d.eps_lin = eps_lin;
   e->d.digest = 1;
+  e->dh.eps_int = eps_int_feas;  // the pool's harvest tile carries its own copy
+  e->dh.eps_lin = eps_lin;
+  e->dh.digest = 1;
   return 0;
 }
 

@@ -190,6 +190,55 @@ class OSQP(object):
             iter=np.array([i.iter for i in infos]), lower=np.array([i.lower for i in infos]),
             run_time=np.array([i.run_time for i in infos]), infos=infos)
 
+    # -- device-resident leaf pool + streaming batch (miosqp_qp_pool_*) ------------------------------
+    POOL_PRUNED = -100
+
+    def pool_create(self, capacity, columns):
+        _check(self._lib.miosqp_qp_pool_create(self._h, int(capacity), int(columns)), "pool_create")
+        self._dg = (_lib.PoolDigest * 8192)()
+        self._dg_np = np.frombuffer(self._dg, dtype=np.dtype(
+            [("slot", "i4"), ("status_val", "i4"), ("iter", "i4"), ("int_inf", "i4"), ("nextvar", "i4"), ("reserved", "i4"),
+             ("lower", "f8"), ("heur_viol", "f8"), ("heur_obj", "f8"), ("pri_res", "f8"), ("dua_res", "f8")]))
+
+    def pool_reset(self):
+        _check(self._lib.miosqp_qp_pool_reset(self._h), "pool_reset")
+
+    def pool_write_node(self, slot, l_int, u_int, x0, y0):
+        k = len(l_int)
+        rc = _check(self._lib.miosqp_qp_pool_write_node(
+            self._h, int(slot), _lib.as_d(_f64(l_int, k, "l_int")), _lib.as_d(_f64(u_int, k, "u_int")),
+            _lib.as_d(_f64(x0, self.n, "x0")), _lib.as_d(_f64(y0, self.m, "y0"))), "pool_write_node")
+        if rc == 1:
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+
+    def pool_read_node(self, slot, n_int, want=("l", "u", "x", "y")):
+        out = dict(l=np.empty(n_int), u=np.empty(n_int), x=np.empty(self.n), y=np.empty(self.m))
+        ptr = [(_lib.as_d(out[k]) if k in want else None) for k in ("l", "u", "x", "y")]
+        _check(self._lib.miosqp_qp_pool_read_node(self._h, int(slot), *ptr), "pool_read_node")
+        return types.SimpleNamespace(**{k: out[k] for k in want})
+
+    def pool_push(self, slot, child0, child1, lower):
+        s = np.ascontiguousarray(slot, dtype=np.int32)
+        c0 = np.ascontiguousarray(child0, dtype=np.int32)
+        c1 = np.ascontiguousarray(child1, dtype=np.int32)
+        lo = np.ascontiguousarray(lower, dtype=np.float64)
+        _check(self._lib.miosqp_qp_pool_push(self._h, len(s), _lib.as_i(s), _lib.as_i(c0), _lib.as_i(c1),
+                                             _lib.as_d(lo)), "pool_push")
+
+    def pool_set_upper(self, upper):
+        _check(self._lib.miosqp_qp_pool_set_upper(self._h, float(min(upper, 1.7e308))), "pool_set_upper")
+
+    def pool_launch(self, chunks=1):
+        _check(self._lib.miosqp_qp_pool_launch(self._h, int(chunks)), "pool_launch")
+
+    def pool_collect(self, keep_in_flight=0):
+        """Waits until at most `keep_in_flight` launches are still running; returns (digests as a numpy record
+        array (a copy), active columns, ready-ring entries not yet taken)."""
+        n, act, left = C.c_int32(), C.c_int32(), C.c_int64()
+        _check(self._lib.miosqp_qp_pool_collect(self._h, int(keep_in_flight), self._dg, 8192, C.byref(n),
+                                                C.byref(act), C.byref(left)), "pool_collect")
+        return self._dg_np[:n.value].copy(), act.value, left.value
+
     # -- introspection ------------------------------------------------------------------------
     def debug_iterate(self, k):
         x, z, y = np.empty(self.n), np.empty(self.m), np.empty(self.m)

@@ -1,0 +1,252 @@
+"""Tree search on the device-resident leaf pool (miosqp_qp_pool_*): the host keeps the search logic, the
+device keeps the leaves.
+
+What stays on the host is what /root/reference/miosqp/workspace.py does with SCALARS: which open leaf next
+(choose_leaf, 128-155), bound test and pruning (274-280, 299-300), incumbent updates (304-327), the return
+status (352-373).  What moved to the device is everything that touches vectors: the leaf's bounds and warm
+start (Workspace.leaves, 83), the relaxation (Node.solve), the clamp and objective (node.py:131-143), the
+integrality test / branching variable / rounding heuristic (workspace.py:205-272) and the creation of the two
+children (add_left / add_right, 157-203).  Per decided node 64 bytes come back (a digest); an incumbent's x is
+fetched when one is found.
+
+The batch is a STREAM: columns are refilled from a ready ring between chunks of `check_termination`
+iterations, so a node never waits for the slowest node of a wave.  Nodes are pushed in the order the
+exploration rule would pick them at push time; as in wave mode the visiting order differs from the
+reference's one-node-at-a-time order, per-node results do not (tests/test_gpu_parity.py).
+"""
+import numpy as np
+
+from miosqp_amd import bnb
+
+PRUNED = -100
+
+
+class StreamSearch(object):
+    def __init__(self, model, columns=256, capacity=None, ring_margin=None, observer=None):
+        self.model = model
+        self.observer = observer  # observer(search, digest): called before a digest is absorbed (tests)
+        self.work = model.work
+        w = self.work
+        self.eng = w.solver
+        if not hasattr(self.eng, "pool_create"):
+            raise TypeError("the streaming search needs the HIP engine (miosqp_amd.qp)")
+        self.columns = int(columns)
+        self.p = w.data.n_int
+        # every column dives on its own, and until the first incumbent nothing can be pruned: on config 2 the first
+        # incumbent sits ~58 levels down, by which time 256 columns have decided ~20 000 nodes, each leaving one
+        # open sibling.  Slots are cheap (config 2: 18 KB each, HBM holds 288 GB): default 65 536 slots, at most 8 GB.
+        slot_bytes = 8 * (w.data.n + w.data.m + 3 * self.p + 1)
+        self.capacity = int(capacity) if capacity else int(max(4096, min(65536, (8 << 30) // slot_bytes)))
+        # ring target = the columns known to be free + this margin: entries are pushed in the exploration rule's
+        # order AT PUSH TIME, so a short ring keeps the choice fresh (a long one commits columns to shallow leaves
+        # chunks ahead and the search degenerates to breadth first)
+        self.margin = int(ring_margin) if ring_margin else max(16, self.columns // 8)
+        self.active = 0
+        if not getattr(self.eng, "_pool_made", False):
+            self.eng.pool_create(self.capacity, self.columns)
+            self.eng._pool_made = True
+            self.eng._pool_capacity = self.capacity
+        self.capacity = self.eng._pool_capacity
+        cap = self.capacity
+        self.depth = np.zeros(cap, dtype=np.int64)
+        self.lower = np.full(cap, -np.inf)       # bound a node inherited; its own once solved
+        self.parent = np.full(cap, -1, dtype=np.int64)
+        self.kids_alive = np.zeros(cap, dtype=np.int64)
+        self.child = np.full((cap, 2), -1, dtype=np.int64)
+        self.nodes = 0
+        self.iters = 0
+        self.dropped = 0
+        self.chunks = 0
+        self.const_solved = w.constant('OSQP_SOLVED')
+        self.const_maxit = w.constant('OSQP_MAX_ITER_REACHED')
+        self._decided = np.zeros(cap, dtype=bool)
+        self.begin_instance()
+
+    # -- instance -------------------------------------------------------------------------------
+    def begin_instance(self):
+        """(Re)starts on the model's current root: call after MIOSQP.update_vectors."""
+        w = self.work
+        self.eng.pool_reset()
+        self._decided[:] = False
+        self.kids_alive[:] = 0
+        self.free = list(range(self.capacity - 1, -1, -1))  # pop() hands out slot 0 first
+        self.open = []        # slots of open leaves not yet pushed, in creation order
+        self.in_flight = 0    # pushed and not yet decided
+        root = w.leaves[0] if w.leaves else w._make_root()
+        s = self.free.pop()
+        self.eng.pool_write_node(s, root.l[-self.p:], root.u[-self.p:], root.x, root.y)
+        self.depth[s] = 0
+        self.lower[s] = root.lower
+        self.parent[s] = -1
+        self.kids_alive[s] = 0
+        self.open.append(s)
+        w.leaves = []
+        self.eng.pool_set_upper(w.upper_glob)
+        self._launched = False
+        self.active = 0
+
+    # -- slots ----------------------------------------------------------------------------------
+    def _done(self, s):
+        """Node `s` has been decided (or discarded).  Its slot stays allocated while a child may still read its
+        solution as a warm start; the last child to be decided frees it.  `s` itself no longer needs its parent."""
+        s = int(s)
+        self._decided[s] = True
+        if self.kids_alive[s] == 0:
+            self.free.append(s)
+        par = int(self.parent[s])
+        if par >= 0:
+            self.kids_alive[par] -= 1
+            if self.kids_alive[par] == 0 and self._decided[par]:
+                self.free.append(par)
+
+    # -- host side of bound_and_branch (workspace.py:282-334) on a digest --------------------------
+    def _absorb(self, g):
+        w = self.work
+        s = int(g["slot"])
+        if self.observer is not None:
+            self.observer(self, g)
+        self.in_flight -= 1
+        c0, c1 = int(self.child[s, 0]), int(self.child[s, 1])
+        st = int(g["status_val"])
+
+        def no_children():
+            for c in (c0, c1):
+                if c >= 0:
+                    self.free.append(c)
+            self.child[s] = -1
+            self.kids_alive[s] = 0
+
+        if st == PRUNED:
+            self.dropped += 1
+            no_children()
+            self._done(s)
+            return
+        self.nodes += 1
+        self.iters += int(g["iter"])
+        w.iter_num += 1
+        w.osqp_iter += int(g["iter"])
+        if st not in (self.const_solved, self.const_maxit):
+            no_children()
+            self._done(s)
+            return
+        lower = float(g["lower"])
+        self.lower[s] = lower
+        if lower > w.upper_glob:
+            no_children()
+            self._done(s)
+            return
+        if int(g["int_inf"]) == 0:
+            w.x = self.eng.pool_read_node(s, self.p, want=("x",)).x
+            w.upper_glob = lower
+            self.eng.pool_set_upper(w.upper_glob)
+            self._prune_open()
+            no_children()
+            self._done(s)
+            return
+        if g["heur_viol"] <= 0.0 and g["heur_obj"] < w.upper_glob:
+            x = self.eng.pool_read_node(s, self.p, want=("x",)).x
+            x_int = w.get_integer_solution(x)
+            obj_int = w.data.compute_obj_val(x_int)  # the host's own value enters upper_glob (bnb.py digest branch)
+            if obj_int < w.upper_glob:
+                w.upper_glob = obj_int
+                w.x = x_int
+                self.eng.pool_set_upper(w.upper_glob)
+                self._prune_open()
+        # both children exist on the device (written by the harvest): they become open leaves
+        alive = 0
+        for c in (c0, c1):
+            if c < 0:
+                continue
+            self.depth[c] = self.depth[s] + 1
+            self.lower[c] = lower
+            self.parent[c] = s
+            self.kids_alive[c] = 0
+            self._decided[c] = False
+            self.open.append(c)
+            alive += 1
+        self.kids_alive[s] = alive
+        self._done(s)
+
+    def _prune_open(self):
+        """Open leaves whose inherited bound exceeds the new incumbent are discarded (workspace.py:274-280;
+        the reference's skip-one traversal quirk is not reproduced: every such leaf goes)."""
+        w = self.work
+        keep = []
+        for s in self.open:
+            if self.lower[s] > w.upper_glob:
+                self._done(s)
+            else:
+                keep.append(s)
+        self.open = keep
+
+    def _push(self, ready_left):
+        """Keeps the ready ring topped up with the leaves the exploration rule would take next."""
+        w = self.work
+        room = (self.columns - self.active) + self.margin - int(ready_left)
+        if room <= 0 or not self.open:
+            return
+        rule = w.settings['tree_explor_rule']
+        op = np.asarray(self.open)
+        if rule == 0 or (rule == 1 and np.isinf(w.upper_glob)):
+            keys = self.depth[op].astype(float)
+        elif rule == 1:
+            keys = self.lower[op]
+        else:
+            raise ValueError('Tree exploring strategy not recognized')
+        order = np.argsort(-keys, kind='stable')
+        take = [int(i) for i in order[:min(room, len(self.free) // 2)]]  # two child slots each
+        if not take:
+            return
+        slots = op[take]
+        c0 = np.empty(len(take), dtype=np.int32)
+        c1 = np.empty(len(take), dtype=np.int32)
+        for k, s in enumerate(slots):
+            c0[k] = self.free.pop()
+            c1[k] = self.free.pop()
+            self.child[s, 0], self.child[s, 1] = c0[k], c1[k]
+        self.eng.pool_push(slots, c0, c1, self.lower[slots])
+        self.in_flight += len(take)
+        taken = set(take)
+        self.open = [s for i, s in enumerate(self.open) if i not in taken]
+
+    # -- driver ---------------------------------------------------------------------------------
+    def step(self, chunks=1):
+        """One round, pipelined one launch deep: a new launch of `chunks` chunks is queued, then the host waits
+        for the launch BEFORE it and absorbs the digests of the nodes decided in that one -- the device always
+        has a launch to work on while the host bounds, prunes and pushes.  Returns the number of leaves still
+        alive (open on the host, waiting in the ring or being solved)."""
+        if not self._launched:
+            self._push(0)
+        self.eng.pool_launch(chunks)
+        self._launched = True
+        self.chunks += chunks
+        # one launch stays in flight while the host works -- except every 64th round, which drains the stream
+        # (a full synchronisation point for tools that hook the runtime; costs one bubble in 64 chunks)
+        self._rounds = getattr(self, "_rounds", 0) + 1
+        dg, self.active, left = self.eng.pool_collect(keep_in_flight=0 if self._rounds % 64 == 0 else 1)
+        for g in dg:
+            self._absorb(g)
+        self._push(left)
+        alive = len(self.open) + self.in_flight
+        if alive == 0 or (self.in_flight == 0 and self.open):
+            # the tree may be closed -- or the host has leaves it could not push: drain the launch in flight first
+            dg, self.active, left = self.eng.pool_collect(keep_in_flight=0)
+            for g in dg:
+                self._absorb(g)
+            self._push(left)
+            alive = len(self.open) + self.in_flight
+            if self.in_flight == 0 and self.open:
+                raise MemoryError("leaf pool exhausted: %d open leaves, %d free slots of %d (raise `capacity`)"
+                                  % (len(self.open), len(self.free), self.capacity))
+        return alive
+
+    def run(self, chunks=1, max_nodes=None):
+        w = self.work
+        cap = w.settings['max_iter_bb'] if max_nodes is None else max_nodes
+        alive = 1
+        while alive > 0 and self.nodes + 1 < cap:
+            alive = self.step(chunks)
+        w.osqp_iter_avg = w.osqp_iter / float(max(1, w.iter_num))
+        w.get_return_status(finished=(alive == 0))
+        w.get_return_solution()
+        return bnb.Results(w.x, w.upper_glob, w.run_time, w.status, w.osqp_solve_time, w.osqp_iter_avg)

@@ -947,3 +947,129 @@ def test_single_rank_torchrun_goes_through_rccl(tmp_path):
     assert (a["nodes"], a["iters_per_node"]) == (b["nodes"], b["iters_per_node"])
     assert 0.6 * a["value"] <= b["value"] <= 1.4 * a["value"]
     assert b["n_gpus"] == 1 and b["roofline"]["kernel"] == a["roofline"]["kernel"]
+
+
+def _stream_checker(pr, stride, seen, ref=None):
+    """observer for StreamSearch: every `stride`-th decided node is replayed through solve_node on a SECOND engine
+    from what the pool holds for it (its integer-row bounds, its parent's solution as warm start) and must
+    match the digest: status, iterations, bound, integrality count, branching variable, heuristic outcome, and
+    the stored solution.  `ref`: that second engine when it exists already (a later MIQP of a sequence must go
+    through update(q=) like the engine under test: the cost scaling is fixed at setup)."""
+    from miosqp_amd import qp
+    A, l, u = problems.extended(pr)
+    m, p = pr["A"].shape[0], len(pr["i_idx"])
+    if ref is None:
+        ref = qp.OSQP()
+        ref.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+        ref.set_integer_rows(pr["i_idx"], m)
+        ref.set_root(l, u, 1e-3, 1e-3)
+    count = [0]
+
+    def obs(search, g):
+        if int(g["status_val"]) == -100:
+            return
+        count[0] += 1
+        if count[0] % stride:
+            return
+        s = int(g["slot"])
+        par = int(search.parent[s])
+        nd = search.eng.pool_read_node(s, p)
+        if par >= 0:
+            ws = search.eng.pool_read_node(par, p, want=("x", "y"))
+            x0, y0 = ws.x, ws.y
+        else:
+            x0, y0 = np.zeros(len(pr["q"])), np.zeros(len(l))
+        l2, u2 = l.copy(), u.copy()
+        l2[m:], u2[m:] = nd.l, nd.u
+        r = ref.solve_node(l2, u2, x0, y0)
+        assert (int(g["status_val"]), int(g["iter"])) == (r.status_val, r.iter), s
+        if r.status_val in (1, -2):
+            assert abs(g["lower"] - r.lower) <= 1e-9 * max(1.0, abs(r.lower))
+            assert rel(nd.x, r.x) <= SOL_TOL and rel(nd.y, r.y) <= SOL_TOL
+            assert int(g["int_inf"]) == r.digest.int_inf
+            frac = np.sort(np.abs(r.x[pr["i_idx"]] - np.round(r.x[pr["i_idx"]])))
+            if len(frac) > 1 and frac[-1] - frac[-2] > 1e-7:
+                assert int(g["nextvar"]) == r.digest.nextvar
+            if abs(r.digest.info_viol) > 1e-7:
+                assert (g["heur_viol"] <= 0) == r.digest.heur_feasible
+            assert abs(g["heur_obj"] - r.digest.heur_obj) <= 1e-9 * max(1.0, abs(r.digest.heur_obj))
+            # the children the device wrote: this node's bounds with one entry changed (workspace.py:157-203)
+            if int(g["int_inf"]) > 0:
+                k = int(g["nextvar"])
+                xv = nd.x[pr["i_idx"][k]]
+                for side, c in enumerate(search.child[s]):
+                    ch = search.eng.pool_read_node(int(c), p, want=("l", "u"))
+                    el, eu = nd.l.copy(), nd.u.copy()
+                    if side == 0:
+                        eu[k] = np.floor(xv)
+                    else:
+                        el[k] = np.ceil(xv)
+                    np.testing.assert_array_equal(ch.l, el)
+                    np.testing.assert_array_equal(ch.u, eu)
+        seen.append(s)
+    obs.ref = ref
+    return obs
+
+
+@pytest.mark.parametrize("n,m,p,seed,cols", [(30, 150, 15, 4, 64), (50, 100, 25, 2, 128), (20, 40, 10, 1, 64)])
+def test_streaming_search_on_the_leaf_pool(n, m, p, seed, cols):
+    """Device-resident leaf pool + streaming batch: the search closes the tree with the
+    sequential search's optimum; every node it decides equals solve_node on the same inputs; the children it
+    generates on the device are the reference's add_left / add_right; a second MIQP on the same factor
+    (update_vectors) reuses the pool."""
+    from miosqp_amd import bnb, stream
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6)
+    seq = bnb.MIOSQP()
+    seq.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS))
+    r0 = seq.solve()
+    model = bnb.MIOSQP()
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+                dict(problems.QP_SETTINGS, max_batch=cols))
+    seen = []
+    srch = stream.StreamSearch(model, columns=cols, observer=_stream_checker(pr, 1, seen))
+    r1 = srch.run()
+    assert r1.status == r0.status == bnb.MI_SOLVED
+    assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+    ii = pr["i_idx"]
+    np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
+    assert len(seen) == srch.nodes >= 1
+    assert len(srch.free) == srch.capacity  # every slot came back
+    # a second instance on the same factor and the same pool
+    rng = np.random.RandomState(seed)
+    q2 = rng.randn(n)
+    for mdl in (seq, model):
+        mdl.update_vectors(q=q2)
+    pr2 = dict(pr, q=q2)
+    srch.observer.ref.update(q=q2)
+    srch.observer = _stream_checker(pr2, 1, seen, ref=srch.observer.ref)
+    srch.begin_instance()
+    r0, r1 = seq.solve(), srch.run()
+    assert r1.status == r0.status == bnb.MI_SOLVED
+    assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+    np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
+
+
+def test_streaming_batch_at_config3_size():
+    """BASELINE config 3 as a stream: n=500, 256 columns kept full from the device-resident pool; a sample of the
+    decided nodes is replayed through solve_node; the columns stay busy (no wave tail)."""
+    from miosqp_amd import bnb, stream
+    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 9)
+    model = bnb.MIOSQP()
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
+                dict(problems.QP_SETTINGS, max_batch=256))
+    seen = []
+    srch = stream.StreamSearch(model, columns=256, observer=_stream_checker(pr, 16, seen))
+    eng = model.work.solver
+    alive, steps = 1, 0
+    while alive and steps < 1500 and srch.nodes < 600:  # the frontier doubles every ~20 chunks (one node's iterations)
+        alive = srch.step()
+        steps += 1
+    assert srch.nodes >= 256 and len(seen) >= 16
+    ms, lock_iters, node_iters = eng.batch_stats()
+    assert lock_iters == 25 * srch.chunks or lock_iters == 25 * (srch.chunks - 1)
+    # useful column-iterations / (columns x lock-step iterations): the stream keeps the columns busy once the
+    # frontier is wide enough (a wave of 256 leaves averages below one half)
+    assert node_iters <= 256 * lock_iters
