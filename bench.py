@@ -265,7 +265,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-width", type=int, default=256,
                     help="extra leg: leaves per batched wave (BASELINE configs[2]); 0 = skip")
-    ap.add_argument("--batch-waves", type=int, default=12)
+    ap.add_argument("--batch-waves", type=int, default=6)
+    ap.add_argument("--stream-warmup", type=int, default=700, help="streaming leg: chunks before the timed stretch")
+    ap.add_argument("--stream-chunks", type=int, default=600, help="streaming leg: timed chunks")
     ap.add_argument("--no-large-leg", action="store_true",
                     help="skip the extra BASELINE configs[4] leg (n=5000, bandwidth-bound single-node ADMM)")
     ap.add_argument("--no-probes", action="store_true",
@@ -386,12 +388,14 @@ def main():
                      mean_nodes_per_tree=round(float(np.mean([c[1] for c in closed[1:]])), 1),
                      trees_per_s=round(1.0 / float(np.mean(gaps)), 2))
 
-    # ---- extra leg (BASELINE configs[2]): the same stream explored in waves of up to `batch_width`
-    #      leaves per rank, each wave ONE batched device call (not part of `value`) -------------------
+    # ---- extra leg (BASELINE configs[2]): the same MIQP stream with `batch_width` leaves in flight per rank
+    #      (not part of `value`).  Two forms: WAVES (each wave one batched device call: a wave waits for its
+    #      slowest leaf, vectors cross PCIe) and the STREAM on the device-resident leaf pool (columns refilled
+    #      between chunks, 64-byte digests back: miosqp_amd/stream.py) -------------------------------------
     batched = None
     if "batched" in legs:
         next_instance()
-        run_steps(12, args.batch_width, True)  # warm-up: graph capture, allocation, frontier ramp-up
+        run_steps(6, args.batch_width, True)  # warm-up: graph capture, allocation, frontier ramp-up
         sync()
         eng.batch_stats(reset=True)
         n1, i1 = srch.nodes, srch.iters
@@ -406,13 +410,51 @@ def main():
             tb = torch.tensor([dtb], dtype=torch.float64, device=comm.device)
             td.all_reduce(tb, op=td.ReduceOp.MAX)
             dtb = float(tb.item())
-        batched = dict(max_wave=args.batch_width, waves=args.batch_waves, nodes=float(totb[1]),
-                       mean_wave=round(float(totb[1]) / max(1, args.batch_waves * world), 1),
-                       node_iters_per_s=round(float(totb[0]) / dtb, 1), nodes_per_s=round(float(totb[1]) / dtb, 2),
-                       lockstep_iters=bit, device_us_per_lockstep_iter=round(1e3 * bms / max(1, bit), 2),
-                       device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
-        batched["end_to_end_over_device"] = round(batched["node_iters_per_s"] /
-                                                  max(1.0, batched["device_node_iters_per_s"] * world), 3)
+        waves = dict(waves=args.batch_waves, nodes=float(totb[1]),
+                     mean_wave=round(float(totb[1]) / max(1, args.batch_waves * world), 1),
+                     node_iters_per_s=round(float(totb[0]) / dtb, 1), nodes_per_s=round(float(totb[1]) / dtb, 2),
+                     lockstep_iters=bit, device_us_per_lockstep_iter=round(1e3 * bms / max(1, bit), 2),
+                     device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
+        waves["end_to_end_over_device"] = round(waves["node_iters_per_s"] /
+                                                max(1.0, waves["device_node_iters_per_s"] * world), 3)
+        # the stream: new MIQP, ramp-up until the columns are busy, then a timed stretch
+        from miosqp_amd import stream as stream_mod
+        next_instance()
+        ss = stream_mod.StreamSearch(model, columns=args.batch_width)
+
+        def stream_steps(count):
+            for _ in range(count):
+                if ss.step() == 0:
+                    next_instance()
+                    ss.begin_instance()
+
+        stream_steps(args.stream_warmup)
+        sync()
+        eng.batch_stats(reset=True)
+        n2, i2, c2 = ss.nodes, ss.iters, ss.chunks
+        t2 = time.perf_counter()
+        stream_steps(args.stream_chunks)
+        eng.pool_collect(0)  # the launch in flight belongs to the timed region (its digests are not counted)
+        sync()
+        dts = time.perf_counter() - t2
+        sms, sit, snode = eng.batch_stats()
+        tots = comm.sum([ss.iters - i2, ss.nodes - n2])
+        if td is not None:
+            tb = torch.tensor([dts], dtype=torch.float64, device=comm.device)
+            td.all_reduce(tb, op=td.ReduceOp.MAX)
+            dts = float(tb.item())
+        batched = dict(width=args.batch_width, form="stream on the device-resident leaf pool",
+                       chunks=ss.chunks - c2, nodes=float(tots[1]),
+                       node_iters_per_s=round(float(tots[0]) / dts, 1), nodes_per_s=round(float(tots[1]) / dts, 2),
+                       iters_per_node=round(float(tots[0]) / max(1.0, float(tots[1])), 1),
+                       lockstep_iters=sit, device_us_per_lockstep_iter=round(1e3 * sms / max(1, sit), 2),
+                       column_occupancy=round(snode / float(max(1, args.batch_width * sit)), 3),
+                       device_node_iters_per_s=round(snode / max(1e-9, sms) * 1e3, 1),
+                       end_to_end_over_device=round(1e-3 * sms / dts, 3),
+                       open_leaves=len(ss.open), pool_slots_free=len(ss.free), dropped_at_refill=ss.dropped,
+                       waves=waves)
+        model.work.leaves = []  # the pool owns the open leaves of this instance
+        next_instance()
 
     if rank == 0:
         fs = eng.factor_stats()
@@ -484,11 +526,27 @@ def main():
         out["config"]["instances_in_timed_region"] = instances
         if batched is not None and batched["lockstep_iters"] > 0:
             bk = []
-            bnames = ["kbm_fwd", "kbm_bwd"] if fs["fold"] else ["kb_" + k[2:] for k in KERNELS]
-            for k, nm in enumerate(bnames):
-                us, by = eng.time_kernel(10 + k, 30)
-                bk.append(dict(kernel=nm, usec=round(us, 2), bytes=by, gbs=round(by / us * 1e-3, 1)))
-            batched["kernels"] = bk
+            if not args.no_probes:
+                bnames = ["kbm_fwd", "kbm_bwd"] if fs["fold"] else ["kb_" + k[2:] for k in KERNELS]
+                for k, nm in enumerate(bnames):
+                    us, by = eng.time_kernel(10 + k, 30)
+                    bk.append(dict(kernel=nm, usec=round(us, 2), bytes=by, gbs=round(by / us * 1e-3, 1)))
+            batched["kernels_full_width_back_to_back"] = bk
+            # SURVEY 8d's config-3 accounting: matrix terms once per lock-step iteration, vector terms per column;
+            # flops: both sweeps, 2 flop per factor entry (product form: n M + n (n - 1) / 2 entries per sweep)
+            nn, MM = cfg["n"], cfg["m"] + cfg["p"]
+            per_col = (6 * nn + 16 * MM) * 8
+            alg = (fs["bytes_per_iter"] - per_col) + per_col * args.batch_width
+            flops = 4.0 * (nn * MM + nn * (nn - 1) / 2) * args.batch_width
+            us = batched["device_us_per_lockstep_iter"]
+            batched["roofline"] = dict(bound="fp64 matrix cores + L2->L1 operand traffic (two dense fp64 GEMMs per iteration, "
+                                             "16 x 32 tiles; the factor is read from L2 / Infinity Cache, not HBM)",
+                                       algorithmic_bytes_per_lockstep_iter=int(alg), achieved_gbs=round(alg / us * 1e-3, 1),
+                                       frac_of_hbm_peak=round(alg / us * 1e-3 / HBM_PEAK_GBS, 4),
+                                       flops_per_lockstep_iter=int(flops), tflops=round(flops / us * 1e-6, 2),
+                                       fp64_mfma_peak_tflops=78.6, frac_of_fp64_peak=round(flops / us * 1e-6 / 78.6, 4),
+                                       note="device time per lock-step iteration includes the per-chunk termination test, "
+                                            "refill and harvest")
             out["batched"] = batched
         if world == 1 and args.config == "cfg2":
             if "stream" in legs:
