@@ -149,6 +149,11 @@ struct Dev {
   int *fmap, *hmap;         // columns refilled / harvested in the current chunk
   double *lt_x;             // load tile: scaled x of the refilled columns, [n][64]
   const int *int_pos;       // variable -> its position in i_idx, or -1
+  // ---- integer-bound rows taken out of the batched products (kernels_batched.inc "identity rows") ----
+  int wh_m;                 // rows of the constraint block that go through the matrix products (m, or M when off)
+  const double *f_rows2;    // [ -G(general rows) | strict_lower(Linv) ], n x ldf2 (== f_rows, ldf when off)
+  int ldf2;
+  const double *a_int;      // per variable: rho * (scaled entry of its bound row), 0 for continuous variables
   double *pl_lo, *pl_hi;    // [cap][n_int] integer-row bounds of every node
   int *pl_ws;               // slot whose solution is the node's warm start
   double *sol_x, *sol_y;    // [cap][n], [cap][M] solutions of solved nodes (x clamped as node.py:131-136)
@@ -309,7 +314,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->nnzPtriu = (int64_t)e->sc.Pi.size();
   const miosqp::Factor &f = e->fa;
   Dev &d = e->d;
-  d.n = n; d.M = M; d.ld = f.ld; d.n_int = 0; d.m_orig = M;
+  d.n = n; d.M = M; d.ld = f.ld; d.n_int = 0; d.m_orig = M; d.wh_m = M;
   d.rho = s->rho; d.rho_inv = 1.0 / s->rho; d.sigma = s->sigma; d.alpha = s->alpha; d.eps_abs = s->eps_abs; d.eps_rel = s->eps_rel;
   d.eps_pinf = s->eps_prim_inf; d.eps_dinf = s->eps_dual_inf; d.c = e->sc.c; d.cinv = e->sc.cinv;
   {
@@ -407,6 +412,8 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       if (rc) { miosqp_qp_cleanup(e); return rc; }
       d.ldf = e->fo.ldf;
       d.ldn = e->fo.ldn;
+      d.f_rows2 = d.f_rows;
+      d.ldf2 = d.ldf;
       e->fold = true;
       e->tpr_ff = pick_tpr(M + 0.5 * n);
       e->tpr_fx = pick_tpr(0.5 * n);
@@ -610,6 +617,38 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
   e->d.n_int = n_int;
   e->d.m_orig = m_orig;
   e->have_int = true;
+  // Identity rows (kernels_batched.inc): when every bound row has exactly one entry, at its variable's column, and
+  // no variable has two, the matrix-core sweeps leave those rows out.  Decided once, before the batched arrays exist.
+  if (e->fold && e->bd_cfg == 0 && n_int > 0 && e->Bcap == 0 && !getenv("MIOSQP_NO_IDROWS")) {
+    const miosqp::PCsr &C = e->fa.panel_by_con;
+    std::vector<double> aint(e->n, 0.0);
+    bool ok = true;
+    for (int k = 0; k < n_int && ok; k++) {
+      const int j = m_orig + k;
+      int cnt = 0, col = -1;
+      double val = 0.0;
+      for (int t = C.ptr[j]; t < C.ptr[j + 1]; t++)
+        if (e->fa.A_val[t] != 0.0) { cnt++; col = C.idx[t]; val = e->fa.A_val[t]; }
+      ok = cnt == 1 && col == i_idx[k] && aint[col] == 0.0;
+      if (ok) aint[col] = e->st.rho * val;
+    }
+    if (ok) {
+      const int n = e->n, m = m_orig;
+      const int ld2 = (m + n + 15) & ~15;
+      double *f2 = nullptr, *ai = nullptr;
+      int rc = dalloc(e, &f2, (size_t)n * ld2 + 64);
+      if (!rc) rc = dalloc(e, &ai, (size_t)n);
+      if (rc) return rc;
+      HIPCHK(hipMemcpy(ai, aint.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_drop_bound_columns, dim3((ld2 + 255) / 256, n), dim3(256), 0, e->stream, e->d.f_rows, e->d.ldf,
+                         f2, ld2, m, n_int, n);
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->d.f_rows2 = f2;
+      e->d.ldf2 = ld2;
+      e->d.a_int = ai;
+      e->d.wh_m = m;
+    }
+  }
   // the captured graphs hold Dev by value but never read n_int / m_orig / i_idx contents
   return 0;
 }
