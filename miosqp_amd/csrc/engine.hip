@@ -233,12 +233,6 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->g_full) hipGraphDestroy(e->g_full);
   if (e->g_tail) hipGraphDestroy(e->g_tail);
   for (void *p : e->allocs) hipFree(p);
-  if (e->h_in) hipHostFree(e->h_in);
-  if (e->h_out) hipHostFree(e->h_out);
-  if (e->h_ctrl) hipHostFree(e->h_ctrl);
-  if (e->h_ctrl2) hipHostFree(e->h_ctrl2);
-  if (e->ev_chunk[0]) hipEventDestroy(e->ev_chunk[0]);
-  if (e->ev_chunk[1]) hipEventDestroy(e->ev_chunk[1]);
   drop_stream_graph(e);
   for (hipEvent_t ev : e->ev_pool)
     if (ev) hipEventDestroy(ev);
@@ -255,11 +249,7 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
     if (e->gb_full[k]) hipGraphDestroy(e->gb_full[k]);
     if (e->gb_tail[k]) hipGraphDestroy(e->gb_tail[k]);
   }
-  if (e->ev0) hipEventDestroy(e->ev0);
-  if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->evc0) hipEventDestroy(e->evc0);
-  if (e->evc1) hipEventDestroy(e->evc1);
-  if (e->stream) hipStreamDestroy(e->stream);
+  rt_release(e->rt);  // stream, events and pinned staging go back to the per-process cache
   delete e;
   return 0;
 }
@@ -293,6 +283,14 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   if (s->device >= 0) HIPCHK(hipSetDevice(s->device));
   miosqp_qp_engine *e = new miosqp_qp_engine();
   HIPCHK(hipGetDevice(&e->device));
+  const bool t_on = getenv("MIOSQP_SETUP_TIMING") != nullptr;
+  double t_last = wall();
+  auto tick = [&](const char *what) {
+    if (!t_on) return;
+    const double now = wall();
+    fprintf(stderr, "[miosqp setup] %-32s %8.3f ms\n", what, 1e3 * (now - t_last));
+    t_last = now;
+  };
   e->n = n;
   e->M = M;
   e->st = *s;
@@ -310,6 +308,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     delete e;
     return MIOSQP_EFACTOR;
   }
+  tick("host: scaling + factor (total)");
   e->nnzA = Ap[n];
   e->nnzPtriu = (int64_t)e->sc.Pi.size();
   const miosqp::Factor &f = e->fa;
@@ -326,6 +325,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     int rc0 = pool_reserve(e, est);
     if (rc0) { miosqp_qp_cleanup(e); return rc0; }
   }
+  tick("device pool: malloc + zero fill");
 #define UP(vec, field)                                   \
   do {                                                   \
     int rc__ = dupload(e, vec, &d.field);                \
@@ -361,17 +361,16 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     d.i_idx = ii;
   }
 #undef AL
-  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreate(&e->ev0));
-  HIPCHK(hipEventCreate(&e->ev1));
-  HIPCHK(hipEventCreate(&e->evc0));
-  HIPCHK(hipEventCreate(&e->evc1));
-  HIPCHK(hipHostMalloc((void **)&e->h_in, sizeof(double) * (2 * (size_t)M + n + M + 1), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void **)&e->h_out, sizeof(double) * ((size_t)n + M + 1), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void **)&e->h_ctrl, sizeof(Ctrl), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void **)&e->h_ctrl2, 2 * sizeof(Ctrl), hipHostMallocDefault));
-  HIPCHK(hipEventCreateWithFlags(&e->ev_chunk[0], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&e->ev_chunk[1], hipEventDisableTiming));
+  tick("uploads (factor, matrices)");
+  {
+    int rcb = rt_acquire(e->device, 2 * (size_t)M + n + M + 1, (size_t)n + M + 1, e->rt);
+    if (rcb) { miosqp_qp_cleanup(e); return rcb; }
+    e->stream = e->rt.stream;
+    e->ev0 = e->rt.ev0; e->ev1 = e->rt.ev1; e->evc0 = e->rt.evc0; e->evc1 = e->rt.evc1;
+    e->ev_chunk[0] = e->rt.ev_chunk[0]; e->ev_chunk[1] = e->rt.ev_chunk[1];
+    e->h_in = e->rt.h_in; e->h_out = e->rt.h_out; e->h_ctrl = e->rt.h_ctrl; e->h_ctrl2 = e->rt.h_ctrl2;
+  }
+  tick("stream, events, pinned buffers");
   // scaled q, raw q, scaled bounds
   HIPCHK(hipMemcpy(d.q, e->sc.q.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.qraw, q, sizeof(double) * n, hipMemcpyHostToDevice));
@@ -510,6 +509,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       std::vector<double>().swap(e->fo.Pd);
     }
   }
+  tick("product form, resident / cooperative set-up");
   e->chunk = e->st.check_termination;
   e->tail_iters = e->st.max_iter % e->chunk;
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -522,6 +522,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     int rc = calibrate_coop_nap(e);
     if (rc) { miosqp_qp_cleanup(e); return rc; }
   }
+  tick("graph capture / calibration");
   *out = e;
   return 0;
 }
