@@ -76,10 +76,14 @@ def load_power_converter(path=None):
     z = np.load(path, allow_pickle=False)
     P = spa.csc_matrix((z["P_data"], z["P_indices"], z["P_indptr"]), shape=tuple(z["P_shape"]))
     A = spa.csc_matrix((z["A_data"], z["A_indices"], z["A_indptr"]), shape=tuple(z["A_shape"]))
-    return dict(P=P, A=A, l=z["l"].copy(), i_idx=z["i_idx"].copy(), i_l=z["i_l"].copy(), i_u=z["i_u"].copy(),
-                settings=json.loads(str(z["settings"])), qp_settings=json.loads(str(z["qp_settings"])),
-                q=z["q"], u=z["u"], x0=z["x0"], x=z["x"], upper=z["upper"], status=[str(s) for s in z["status"]],
-                nodes=z["nodes"], osqp_iter=z["osqp_iter"])
+    pc = dict(P=P, A=A, l=z["l"].copy(), i_idx=z["i_idx"].copy(), i_l=z["i_l"].copy(), i_u=z["i_u"].copy(),
+              settings=json.loads(str(z["settings"])), qp_settings=json.loads(str(z["qp_settings"])),
+              q=z["q"], u=z["u"], x0=z["x0"], x=z["x"], upper=z["upper"], status=[str(s) for s in z["status"]],
+              nodes=z["nodes"], osqp_iter=z["osqp_iter"])
+    for k in ("U", "Y_phase", "t", "init_periods", "sim_periods", "Nstpp", "freq", "fsw", "thd"):
+        if k in z.files:  # the long fixture: closed-loop signals + the statistics the reference computed from them
+            pc[k] = z[k] if z[k].ndim else z[k].item()
+    return pc
 
 
 def run_power_converter(pc, backend, steps=None, model=None):
@@ -101,5 +105,6 @@ def run_power_converter(pc, backend, steps=None, model=None):
         model.set_x0(pc["x0"][k].copy())
         res = model.solve()
         out.append(dict(x=np.array(res.x, dtype=float), upper=res.upper_glob, status=res.status,
-                        nodes=model.work.iter_num - 1, osqp_iter=model.work.osqp_iter))
+                        nodes=model.work.iter_num - 1, osqp_iter=model.work.osqp_iter, run_time=res.run_time,
+                        osqp_solve_time=res.osqp_solve_time, osqp_iter_avg=res.osqp_iter_avg))
     return out, model
