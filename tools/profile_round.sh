@@ -14,9 +14,14 @@ db() { find $1 -name "*.db" | head -1; }
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 
 cd /tmp
-# 2. kernel trace of the same default command (all legs; CPU baseline skipped: no GPU work in it)
+# 2. kernel trace of the same default command (all legs; CPU baseline skipped: no GPU work in it).
+#    MIOSQP_POOL_NOGRAPH=1: the streaming leg launches its chunk kernel by kernel (rocprofv3 dies inside
+#    hipGraphLaunch after ~230 replays of that graph); same kernels, same device time
+export MIOSQP_POOL_NOGRAPH=1
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/p_all -o all -- python $R/bench.py --no-cpu-baseline > $O/ks_all_bench.json 2> $O/ks_all.err
 python $R/tools/rocpd_stats.py $(db /tmp/p_all) "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (MI355X, $TAG, all legs)" "durations in ns; profiled runs are slower than un-profiled ones" > $O/rocprofv3_kernel_stats.txt
+
+unset MIOSQP_POOL_NOGRAPH
 
 # 3. node launches only: every k_coop dispatch is one node relaxation of the timed workload (no calibration,
 #    no back-to-back probes, no other leg); avg duration / iterations per launch follow from this file + its JSON
@@ -53,10 +58,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/pmc_merge.py $O/pmc_c5_FETCH_SIZE.json $O/pmc_c5_WRITE_SIZE.json "python bench.py $C5" > $O/pmc_traffic_cfg5.json
 
-# 6. the batched leg alone (config 3)
+# 6. the batched leg alone (config 3: waves, then the stream on the leaf pool)
+export MIOSQP_POOL_NOGRAPH=1
 B3="--steps 20 --warmup 5 --legs batched --no-probes"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_b3 -o s -- python $R/bench.py $B3 > $O/bench_batched.json 2> $O/ks_b3.err
-python $R/tools/rocpd_stats.py $(db /tmp/p_b3) "rocprofv3 --kernel-trace --stats -- python bench.py $B3   (MI355X, $TAG, config 3: waves of 256 leaves)" > $O/rocprofv3_kernel_stats_batched.txt
+python $R/tools/rocpd_stats.py $(db /tmp/p_b3) "rocprofv3 --kernel-trace --stats -- python bench.py $B3   (MI355X, $TAG, config 3: 256 leaves in flight, waves then stream; MIOSQP_POOL_NOGRAPH=1)" > $O/rocprofv3_kernel_stats_batched.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/p_b3_$C -o c -- python $R/bench.py $B3 > /dev/null 2> $O/pmc_b3_$C.err
   python $R/tools/rocpd_pmc.py $(db /tmp/p_b3_$C) > $O/pmc_b3_$C.json

@@ -8,8 +8,11 @@ data; they are counted separately ("early_exit_dispatches") and left out of the 
 them when its counter value is below 30 % of the kernel's median and the kernel's smallest value is.
 """
 import json
+import re
 import sqlite3
 import sys
+
+CHUNK_KERNELS = re.compile(r"(k_panel_|k_tail_|k_fold_|k_check_)")  # see tools/rocpd_stats.py
 
 
 def main():
@@ -24,7 +27,7 @@ def main():
         vs.sort()
         med = vs[len(vs) // 2]
         early = 0
-        if med > 0 and vs[0] < 0.3 * med:
+        if CHUNK_KERNELS.search(name) and med > 0 and vs[0] < 0.3 * med:
             early = sum(1 for v in vs if v < 0.3 * med)
             vs = [v for v in vs if v >= 0.3 * med]
         out.setdefault(name, {})[ctr] = dict(dispatches=len(vs), mean=sum(vs) / float(len(vs)), min=vs[0], max=vs[-1],

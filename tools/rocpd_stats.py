@@ -6,10 +6,15 @@
 Launches that returned at once are listed on their own line ("<kernel> [early exit]"): the multi-kernel
 forms keep one chunk of launches queued ahead of the host's decision, and every kernel of a chunk queued
 behind a decided test returns on `ctrl->done` after ~1.5 us.  A kernel's dispatches are split when its
-shortest one is below 30 % of its median; the threshold is 30 % of the median.
+shortest one is below 30 % of its median; the threshold is 30 % of the median.  Only the kernels of such chunks
+(k_panel_*, k_tail_*, k_fold_*, k_check_*) are split: a short k_coop launch is a node with few iterations.
 """
+import re
 import sqlite3
 import sys
+
+# only the kernels of a queued-ahead chunk can return at once; a short k_coop launch is a short node, not an early exit
+CHUNK_KERNELS = re.compile(r"(k_panel_|k_tail_|k_fold_|k_check_)")
 
 
 def main():
@@ -21,7 +26,7 @@ def main():
     for name, ds in per.items():
         ds.sort()
         med = ds[len(ds) // 2]
-        if ds[0] < 0.3 * med:
+        if CHUNK_KERNELS.search(name) and ds[0] < 0.3 * med:
             full = [d for d in ds if d >= 0.3 * med]
             early = [d for d in ds if d < 0.3 * med]
             rows.append((name, full))
