@@ -38,6 +38,7 @@ extern "C" {
 #define MIOSQP_EHIP (-2)      /* a HIP runtime call failed; see miosqp_qp_last_error() */
 #define MIOSQP_EFACTOR (-3)   /* KKT factorisation broke down (non-convex P?) */
 #define MIOSQP_ENODEV (-4)    /* no usable gfx950 device */
+#define MIOSQP_EUNSUPPORTED (-5) /* the entry point does not cover this problem size / engine form (caller falls back) */
 #define MIOSQP_EBOUNDS 1      /* update_bounds: some l[i] > u[i]; nothing was changed */
 
 /* Solver parameters = the keyword arguments the reference forwards verbatim to
@@ -146,6 +147,29 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u,
 int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const double *u,
                           const double *x0, const double *y0, double *x_out, double *y_out,
                           miosqp_qp_info *info);
+
+/* ---- a whole tree search in one launch (small problems) ------------------------------------------------
+ * the MPC re-solve path (/root/reference/miosqp/solver.py:65-172 per MIQP,
+ * examples/power_converter/power_converter.py:421-508 per sampling step).  For problems the LDS-resident solver
+ * handles, the loop `while can_continue: choose_leaf -> Node.solve -> bound_and_branch` runs inside ONE launch of
+ * one workgroup with the host logic's exact decisions (miosqp_amd/csrc/kernels_tree.inc); the host sends the root
+ * and gets the incumbent back.  Returns MIOSQP_EUNSUPPORTED when the problem is too large for that form. */
+typedef struct miosqp_tree_info {
+  int32_t nodes;        /* nodes visited = iter_num - 1 */
+  int32_t osqp_iter;    /* ADMM iterations over all of them */
+  int32_t leaves_left;  /* open leaves when the loop ended (0: the tree is closed) */
+  int32_t overflow;     /* 1: more than 1024 leaves alive -- the result is not usable, redo on the host */
+  int32_t max_leaves;
+  int32_t found;        /* 1: an incumbent was found in this launch (x_out holds it) */
+  double upper_glob, lower_glob;
+  double device_time, run_time;
+} miosqp_tree_info;
+
+/* l, u, x0, y0: the root node (M, M, n, M doubles); upper0 / x_inc0: incumbent from MIOSQP.set_x0 (x_inc0 NULL or
+ * upper0 >= 1.7e308: none); tree_explor_rule, max_iter_bb: the B&B settings; branching_rule 0 is implied. */
+int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, const double *x0, const double *y0,
+                         double upper0, const double *x_inc0, int32_t tree_explor_rule, int32_t max_iter_bb,
+                         double *x_out, miosqp_tree_info *info);
 
 /* ---- device-resident leaf pool + streaming batch -------------------------------------------------------
  * Workspace.leaves and child generation (/root/reference/miosqp/workspace.py:83,

@@ -30,6 +30,12 @@ class Info(C.Structure):
                 ("heur_obj", C.c_double)]
 
 
+class TreeInfo(C.Structure):
+    _fields_ = [("nodes", C.c_int32), ("osqp_iter", C.c_int32), ("leaves_left", C.c_int32), ("overflow", C.c_int32),
+                ("max_leaves", C.c_int32), ("found", C.c_int32), ("upper_glob", C.c_double), ("lower_glob", C.c_double),
+                ("device_time", C.c_double), ("run_time", C.c_double)]
+
+
 class PoolDigest(C.Structure):
     _fields_ = [("slot", C.c_int32), ("status_val", C.c_int32), ("iter", C.c_int32), ("int_inf", C.c_int32),
                 ("nextvar", C.c_int32), ("reserved", C.c_int32), ("lower", C.c_double), ("heur_viol", C.c_double),
@@ -51,6 +57,8 @@ SYMBOLS = {
     "miosqp_qp_solve_node": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, C.POINTER(Info)]),
     "miosqp_qp_solve_batch": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp,
                                         C.POINTER(Info)]),
+    "miosqp_qp_solve_tree": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.c_double, dp, C.c_int32, C.c_int32, dp,
+                                       C.POINTER(TreeInfo)]),
     "miosqp_qp_pool_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "miosqp_qp_pool_reset": (C.c_int, [C.c_void_p]),
     "miosqp_qp_pool_write_node": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp]),

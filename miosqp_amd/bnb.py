@@ -430,6 +430,8 @@ class MIOSQP(object):
         verbose = work.settings['verbose']
         if verbose:
             work.print_headline()
+        if observer is None and not verbose:
+            self._solve_on_device(work)
         while work.can_continue():
             leaf = work.choose_leaf(work.settings['tree_explor_rule'])
             leaf.solve()
@@ -454,6 +456,39 @@ class MIOSQP(object):
             print("Elapsed time: %.4es" % work.run_time)
         return Results(work.x, work.upper_glob, work.run_time, work.status,
                        work.osqp_solve_time, work.osqp_iter_avg)
+
+    def _solve_on_device(self, work):
+        """Small problems (the LDS-resident engine form; BASELINE config 4): the whole loop below runs inside ONE
+        device launch with the same decisions (`miosqp_qp_solve_tree`, csrc/kernels_tree.inc); the host only sends
+        the root and reads the outcome.  Falls through to the host loop when the engine does not cover the problem
+        (too large, no device digest) or the leaf list overflowed.  settings['device_tree'] = False keeps the host loop."""
+        st = work.settings
+        if not st.get('device_tree', True) or not hasattr(work.solver, 'solve_tree') or getattr(work, '_no_tree', False):
+            return
+        if st['branching_rule'] != 0 or st['tree_explor_rule'] not in (0, 1) or len(work.leaves) != 1 \
+                or work.iter_num != 1 or work.data.n_int == 0 or 'eps_abs' not in work.qp_settings \
+                or not st.get('device_digest', True):
+            return
+        root = work.leaves[0]
+        have = np.isfinite(work.upper_glob)
+        r = work.solver.solve_tree(root.l, root.u, root.x, root.y, work.upper_glob, work.x if have else None,
+                                   st['tree_explor_rule'], st['max_iter_bb'])
+        if r is None:
+            work._no_tree = True  # this engine form never will: do not ask again
+            return
+        if r.info.overflow:
+            return  # more leaves alive than the launch holds: the host loop redoes the search from the root
+        work.iter_num = r.info.nodes + 1
+        work.osqp_iter = r.info.osqp_iter
+        work.osqp_solve_time = r.info.device_time
+        work.upper_glob = r.info.upper_glob
+        work.lower_glob = r.info.lower_glob
+        if r.info.found:
+            work.x = r.x
+        # the leaves live on the device; what matters afterwards is whether any is left (node cap reached)
+        work.leaves = [] if r.info.leaves_left == 0 else [root] * int(r.info.leaves_left)
+        if work.leaves:
+            work.iter_num = max(work.iter_num, st['max_iter_bb'])
 
     def update_vectors(self, q=None, l=None, u=None):
         # solver.py:174-205: same factorisation, new root, statistics reset

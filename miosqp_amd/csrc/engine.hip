@@ -180,6 +180,7 @@ struct Dev {
 #include "kernels_resident.inc"  // LDS-resident single-workgroup solver (k_resident)
 #include "kernels_node.inc"  // per-solve prologue / epilogue kernels (scaling, warm start, finish, node digest, objective)
 #include "kernels_batched.inc"  // batched mode: sparse row kernels, dense vector-FMA tiles, fp64 matrix-core tiles, batched test
+#include "kernels_tree.inc"  // a whole branch-and-bound tree in one launch (LDS-resident problems)
 #include "kernels_pool.inc"  // device-resident leaf pool, streaming batch (refill / harvest between chunks)
 #include "host.inc"  // host side: engine object, allocation, launches, graph capture, solve loops
 #include "host_pool.inc"  // host side of the leaf pool (C ABI miosqp_qp_pool_*)
@@ -729,6 +730,89 @@ int miosqp_qp_solve_batch(miosqp_qp_engine *e, int32_t B, const double *l, const
                          info + s0);
     if (rc) return rc;
   }
+  return 0;
+}
+
+int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, const double *x0, const double *y0,
+                         double upper0, const double *x_inc0, int32_t tree_explor_rule, int32_t max_iter_bb,
+                         double *x_out, miosqp_tree_info *info) {
+  if (!e || !l || !u || !x0 || !y0 || !x_out || !info || max_iter_bb < 1 || tree_explor_rule < 0 || tree_explor_rule > 1)
+    return MIOSQP_EARG;
+  ENTER(e);
+  if (!e->have_int || !e->d.digest) {
+    g_err = "solve_tree: call miosqp_qp_set_integer_rows and miosqp_qp_set_root first";
+    return MIOSQP_EARG;
+  }
+  const int n = e->n, M = e->M, p = e->d.n_int;
+  const size_t lds = tree_lds_doubles(n, M) * sizeof(double);
+  if (!e->fold || lds > 160 * 1024 || p < 1) {  // whatever form single nodes use: the product-form rows must exist and fit
+    g_err = "solve_tree: only for problems whose product-form factor, iterates and leaf list fit 160 KB of LDS";
+    return MIOSQP_EUNSUPPORTED;
+  }
+  for (int i = 0; i < M; i++)
+    if (l[i] > u[i]) return MIOSQP_EBOUNDS;
+  const double t0 = wall();
+  if (!e->tree_ready) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int rc = dalloc(e, &e->ta.lf_lo, (size_t)TREE_CAP * p);
+    if (!rc) rc = dalloc(e, &e->ta.lf_hi, (size_t)TREE_CAP * p);
+    if (!rc) rc = dalloc(e, &e->ta.lf_x, (size_t)TREE_CAP * n);
+    if (!rc) rc = dalloc(e, &e->ta.lf_y, (size_t)TREE_CAP * M);
+    if (!rc) rc = dalloc(e, &e->ta.inc_x, (size_t)n);
+    if (!rc) rc = dalloc(e, &e->ta.out, 1);
+    if (rc) return rc;
+    e->tree_ready = true;
+  }
+  memcpy(e->h_in, l, sizeof(double) * M);
+  memcpy(e->h_in + M, u, sizeof(double) * M);
+  memcpy(e->h_in + 2 * (size_t)M, x0, sizeof(double) * n);
+  memcpy(e->h_in + 2 * (size_t)M + n, y0, sizeof(double) * M);
+  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * (3 * (size_t)M + n), hipMemcpyHostToDevice, e->stream));
+  const bool have_inc = x_inc0 != nullptr && upper0 < 1.7e308;
+  if (have_inc) {
+    memcpy(e->h_out, x_inc0, sizeof(double) * n);
+    HIPCHK(hipMemcpyAsync(e->ta.inc_x, e->h_out, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+  }
+  TreeArgs ta = e->ta;
+  ta.rule = tree_explor_rule;
+  ta.max_nodes = max_iter_bb;
+  ta.max_iter = e->st.max_iter;
+  ta.check_every = e->st.check_termination;
+  {  // lanes per row of the two sweeps, as the LDS-resident solver picks them
+    auto pow2_floor = [](int v) { int q = 1; while (2 * q <= v) q *= 2; return q; };
+    ta.TG1 = std::min(64, std::max(1, pow2_floor(RES_THREADS / n)));
+    ta.TG2 = std::min(64, std::max(1, pow2_floor(RES_THREADS / (n + M))));
+  }
+  ta.upper0 = have_inc ? upper0 : 1.0 / 0.0;
+  hipLaunchKernelGGL(k_tree, dim3(1), dim3(RES_THREADS), lds, e->stream, e->d, ta);
+  HIPCHK(hipMemcpyAsync(e->h_out, e->ta.inc_x, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+  static_assert(sizeof(TreeOut) <= sizeof(Ctrl), "TreeOut travels through the pinned control block");
+  HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ta.out, sizeof(TreeOut), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  if (e->spin_wait) {
+    hipError_t q;
+    while ((q = hipEventQuery(e->ev1)) == hipErrorNotReady) {}
+    if (q != hipSuccess) HIPCHK(q);
+  } else {
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  const TreeOut *o = reinterpret_cast<const TreeOut *>(e->h_ctrl);
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  info->nodes = o->nodes;
+  info->osqp_iter = o->osqp_iter;
+  info->leaves_left = o->leaves_left;
+  info->overflow = o->overflow;
+  info->max_leaves = o->max_leaves;
+  info->found = o->found;
+  info->upper_glob = o->upper;
+  info->lower_glob = o->lower_glob;
+  info->device_time = 1e-3 * ms;
+  info->run_time = wall() - t0;
+  if (o->found || have_inc) memcpy(x_out, o->found ? e->h_out : x_inc0, sizeof(double) * n);
+  e->loop_ms += ms;
+  e->loop_iters += o->osqp_iter;
   return 0;
 }
 

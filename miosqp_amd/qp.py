@@ -190,6 +190,23 @@ class OSQP(object):
             iter=np.array([i.iter for i in infos]), lower=np.array([i.lower for i in infos]),
             run_time=np.array([i.run_time for i in infos]), infos=infos)
 
+    def solve_tree(self, l, u, x0, y0, upper0, x_inc0, tree_explor_rule, max_iter_bb):
+        """A whole tree search in one launch (small problems); None when the engine does not cover this size."""
+        l, u = _f64(l, self.m, "l"), _f64(u, self.m, "u")
+        x0, y0 = _f64(x0, self.n, "x0"), _f64(y0, self.m, "y0")
+        have = x_inc0 is not None and np.isfinite(upper0)
+        xin = _f64(x_inc0, self.n, "x_inc0") if have else None
+        x, info = np.empty(self.n), _lib.TreeInfo()
+        rc = self._lib.miosqp_qp_solve_tree(self._h, _lib.as_d(l), _lib.as_d(u), _lib.as_d(x0), _lib.as_d(y0),
+                                            float(upper0) if have else float("inf"), _lib.as_d(xin) if have else None,
+                                            int(tree_explor_rule), int(max_iter_bb), _lib.as_d(x), C.byref(info))
+        if rc == -5:
+            return None
+        _check(rc, "solve_tree")
+        if rc == 1:
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+        return types.SimpleNamespace(x=x, info=info)
+
     # -- device-resident leaf pool + streaming batch (miosqp_qp_pool_*) ------------------------------
     POOL_PRUNED = -100
 

@@ -1073,3 +1073,35 @@ def test_streaming_batch_at_config3_size():
     # useful column-iterations / (columns x lock-step iterations): the stream keeps the columns busy once the
     # frontier is wide enough (a wave of 256 leaves averages below one half)
     assert node_iters <= 256 * lock_iters
+
+
+@pytest.mark.parametrize("name", [c for c in case_names() if "x0" in c or "n10" in c or "n12" in c or "n20" in c or "mpc" in c])
+def test_whole_tree_in_one_launch_follows_the_reference_traces(name):
+    """miosqp_qp_solve_tree (csrc/kernels_tree.inc): the small golden cases -- trees the REFERENCE explored, recorded
+    node by node -- solved in one launch each end with the reference's node count, iteration count, incumbent
+    and status, for both exploration rules, with set_x0 incumbents and update_vectors sequences."""
+    from miosqp_amd import bnb, qp
+    case = load_case(name)
+    prob = case["prob"]
+    model = bnb.MIOSQP(backend=qp)
+    model.setup(prob["P"], prob["q"], prob["A"], np.copy(prob["l"]), np.copy(prob["u"]), prob["i_idx"], prob["i_l"],
+                prob["i_u"], case["settings"], case["qp_settings"])
+    if case["x0"] is not None:
+        model.set_x0(np.copy(case["x0"]))
+    runs = [(None, None)] + [(u_, x0u) for u_ in case["updates"] for x0u in [u_[3]]]
+    for k, (upd, x0u) in enumerate(runs):
+        if upd is not None:
+            model.update_vectors(q=upd[0], l=upd[1], u=upd[2])
+            if x0u is not None:
+                model.set_x0(np.copy(x0u))
+        res = model.solve()
+        exp = case["solves"][k]
+        used_tree = not getattr(model.work, "_no_tree", False)
+        assert used_tree, "these cases are small enough for the LDS-resident form"
+        assert res.status == exp["status"]
+        assert model.work.iter_num == exp["iter_num"] and model.work.osqp_iter == exp["osqp_iter"]
+        if np.isfinite(exp["upper_glob"]):
+            assert abs(res.upper_glob - exp["upper_glob"]) <= 1e-8 * max(1.0, abs(exp["upper_glob"]))
+            np.testing.assert_allclose(res.x, exp["x"], rtol=0, atol=1e-7)
+        else:
+            assert not np.isfinite(res.upper_glob)
