@@ -752,6 +752,21 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
   for (int i = 0; i < M; i++)
     if (l[i] > u[i]) return MIOSQP_EBOUNDS;
   const double t0 = wall();
+  // n + M <= 64: the whole search in ONE wavefront on the explicit KKT inverse (k_tree_w); MIOSQP_TREE_WAVE=0 keeps k_tree
+  const bool wave = n + M <= TW && !(getenv("MIOSQP_TREE_WAVE") && atoi(getenv("MIOSQP_TREE_WAVE")) == 0);
+  if (wave && !e->d.W) {  // an engine in the LDS-resident form has not built W / Kc yet
+    Dev &d = e->d;
+    const int N = n + M;
+    d.ldw = (N + 7) & ~7;
+    double *Wd = nullptr, *Kc = nullptr;
+    int rcw = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
+    if (!rcw) rcw = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
+    if (!rcw) rcw = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
+    if (rcw) return rcw;
+    d.W = Wd;
+    d.Kc = Kc;
+    hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
+  }
   if (!e->tree_ready) {
     HIPCHK(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int rc = dalloc(e, &e->ta.lf_lo, (size_t)TREE_CAP * p);
@@ -785,7 +800,8 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     ta.TG2 = std::min(64, std::max(1, pow2_floor(RES_THREADS / (n + M))));
   }
   ta.upper0 = have_inc ? upper0 : 1.0 / 0.0;
-  hipLaunchKernelGGL(k_tree, dim3(1), dim3(RES_THREADS), lds, e->stream, e->d, ta);
+  if (wave) hipLaunchKernelGGL(k_tree_w, dim3(1), dim3(TW), 0, e->stream, e->d, ta);
+  else hipLaunchKernelGGL(k_tree, dim3(1), dim3(RES_THREADS), lds, e->stream, e->d, ta);
   HIPCHK(hipMemcpyAsync(e->h_out, e->ta.inc_x, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
   static_assert(sizeof(TreeOut) <= sizeof(Ctrl), "TreeOut travels through the pinned control block");
   HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ta.out, sizeof(TreeOut), hipMemcpyDeviceToHost, e->stream));
