@@ -37,10 +37,11 @@ class StreamSearch(object):
         # open sibling.  Slots are cheap (config 2: 18 KB each, HBM holds 288 GB): default 65 536 slots, at most 8 GB.
         slot_bytes = 8 * (w.data.n + w.data.m + 3 * self.p + 1)
         self.capacity = int(capacity) if capacity else int(max(4096, min(65536, (8 << 30) // slot_bytes)))
-        # ring target = the columns known to be free + this margin: entries are pushed in the exploration rule's
-        # order AT PUSH TIME, so a short ring keeps the choice fresh (a long one commits columns to shallow leaves
-        # chunks ahead and the search degenerates to breadth first)
-        self.margin = int(ring_margin) if ring_margin else max(16, self.columns // 8)
+        # ring target = the columns known to be free + this margin.  Entries are pushed in the exploration rule's
+        # order AT PUSH TIME: a long ring commits columns to shallow leaves chunks ahead (with columns + columns the
+        # search degenerates to breadth first), a short one runs dry -- the host's view of the free columns is one
+        # launch old.  Config 2, 256 columns: occupancy 0.82 / 0.87 / 0.95 / 1.00 at margin 16 / 32 / 64 / 128.
+        self.margin = int(ring_margin) if ring_margin else max(32, self.columns // 2)
         self.active = 0
         if not getattr(self.eng, "_pool_made", False):
             self.eng.pool_create(self.capacity, self.columns)

@@ -1011,12 +1011,14 @@ def _stream_checker(pr, stride, seen, ref=None):
     return obs
 
 
-@pytest.mark.parametrize("n,m,p,seed,cols", [(30, 150, 15, 4, 64), (50, 100, 25, 2, 128), (20, 40, 10, 1, 64)])
-def test_streaming_search_on_the_leaf_pool(n, m, p, seed, cols):
+@pytest.mark.parametrize("n,m,p,seed,cols,fold", [(30, 150, 15, 4, 64, -1), (50, 100, 25, 2, 128, -1), (20, 40, 10, 1, 64, -1),
+                                                   (30, 150, 15, 4, 64, 0), (40, 60, 20, 7, 192, 0)])
+def test_streaming_search_on_the_leaf_pool(n, m, p, seed, cols, fold):
     """Device-resident leaf pool + streaming batch: the search closes the tree with the
     sequential search's optimum; every node it decides equals solve_node on the same inputs; the children it
     generates on the device are the reference's add_left / add_right; a second MIQP on the same factor
-    (update_vectors) reuses the pool."""
+    (update_vectors) reuses the pool.  fold = 0: the factor-form batched kernels (four launches per iteration, the
+    form config 5 uses) instead of the matrix-core tiles."""
     from miosqp_amd import bnb, stream
     pr = problems.random_miqp(n, m, p, seed=seed)
     st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6)
@@ -1026,7 +1028,8 @@ def test_streaming_search_on_the_leaf_pool(n, m, p, seed, cols):
     r0 = seq.solve()
     model = bnb.MIOSQP()
     model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
-                dict(problems.QP_SETTINGS, max_batch=cols))
+                dict(problems.QP_SETTINGS, max_batch=cols, fold=fold))
+    assert model.work.solver.factor_stats()["fold"] == (fold != 0)
     seen = []
     srch = stream.StreamSearch(model, columns=cols, observer=_stream_checker(pr, 1, seen))
     r1 = srch.run()

@@ -11,7 +11,8 @@ pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
 st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 9)
 model = bnb.MIOSQP()
 model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st, dict(problems.QP_SETTINGS, max_batch=cols))
-srch = stream.StreamSearch(model, columns=cols)
+margin = int(os.environ.get('STREAM_MARGIN', '0')) or None
+srch = stream.StreamSearch(model, columns=cols, ring_margin=margin)
 eng = model.work.solver
 rng = np.random.RandomState(12345)
 def reroot():
