@@ -60,3 +60,108 @@ class OSQP(oracle.OSQP):
             status_val=np.array([r.status_val for r in rs]), iter=np.array([r.iter for r in rs]),
             lower=np.array([np.nan if r.lower is None else r.lower for r in rs]),
             run_time=np.array([r.run_time for r in rs]), digest=[r.digest for r in rs])
+
+    # ---- CPU emulation of the leaf pool / streaming batch (miosqp_qp_pool_*): same call surface and semantics as
+    #      miosqp_amd.qp -- slots, ready ring with drop-at-refill, at most 64 refills and harvests per chunk, nodes
+    #      that take a node-dependent number of chunks, children written at harvest, digests handed out on collect,
+    #      one launch possibly still in flight -- with the oracle doing the relaxations.  Test infrastructure only.
+    POOL_PRUNED = -100
+
+    def pool_create(self, capacity, columns):
+        self._pc = dict(cap=int(capacity), cols=int(columns))
+        self.pool_reset()
+
+    def pool_reset(self):
+        pc = self._pc
+        pc.update(lo={}, hi={}, ws={}, sol={}, ring=[], upper=np.inf, cols_state=[None] * pc["cols"], launched=[],
+                  chunk=0)
+
+    def pool_write_node(self, slot, l_int, u_int, x0, y0):
+        pc = self._pc
+        pc["lo"][slot], pc["hi"][slot] = np.array(l_int, dtype=float), np.array(u_int, dtype=float)
+        pc["sol"][slot] = (np.array(x0, dtype=float), np.array(y0, dtype=float))
+        pc["ws"][slot] = slot
+
+    def pool_read_node(self, slot, n_int, want=("l", "u", "x", "y")):
+        pc = self._pc
+        vals = dict(l=pc["lo"].get(slot), u=pc["hi"].get(slot), x=pc["sol"].get(slot, (None, None))[0],
+                    y=pc["sol"].get(slot, (None, None))[1])
+        return types.SimpleNamespace(**{k: np.array(vals[k]) for k in want})
+
+    def pool_push(self, slot, child0, child1, lower):
+        for s, c0, c1, lo in zip(slot, child0, child1, lower):
+            self._pc["ring"].append((int(s), int(c0), int(c1), float(lo)))
+
+    def pool_set_upper(self, upper):
+        self._pc["upper"] = float(upper)
+
+    def _pool_chunk(self):
+        """One chunk: refill (<= 64, dropping entries whose bound exceeds the incumbent), one chunk of progress for
+        every column, harvest (<= 64) of the columns whose node is decided."""
+        pc = self._pc
+        out = []
+        refills = 0
+        for b in range(pc["cols"]):
+            while pc["cols_state"][b] is None and pc["ring"] and refills < 64:
+                s, c0, c1, lo = pc["ring"].pop(0)
+                if lo > pc["upper"]:
+                    out.append(dict(slot=s, status_val=self.POOL_PRUNED, iter=0, int_inf=-1, nextvar=-1, lower=lo,
+                                    heur_viol=np.nan, heur_obj=np.nan))
+                    continue
+                ws = pc["ws"][s]
+                l = np.concatenate([self._root[0][:self._m], pc["lo"][s]])
+                u = np.concatenate([self._root[1][:self._m], pc["hi"][s]])
+                r = self.solve_node(l, u, pc["sol"][ws][0].copy(), pc["sol"][ws][1].copy())
+                chunks = max(1, -(-int(r.iter) // 25))  # the node occupies its column for that many chunks
+                pc["cols_state"][b] = [s, c0, c1, r, chunks]
+                refills += 1
+        harvested = 0
+        for b in range(pc["cols"]):
+            stt = pc["cols_state"][b]
+            if stt is None:
+                continue
+            stt[4] -= 1
+            if stt[4] > 0 or harvested >= 64:
+                stt[4] = max(stt[4], 0)
+                continue
+            s, c0, c1, r, _ = stt
+            harvested += 1
+            pc["cols_state"][b] = None
+            ok = r.status_val in (1, -2)
+            pc["sol"][s] = (np.array(r.x), np.array(r.y))
+            dg = r.digest
+            if ok and dg is not None and dg.int_inf > 0:
+                xv = r.x[self._ii[dg.nextvar]]
+                for c, side in ((c0, 0), (c1, 1)):
+                    if c < 0:
+                        continue
+                    lo_c, hi_c = pc["lo"][s].copy(), pc["hi"][s].copy()
+                    if side == 0:
+                        hi_c[dg.nextvar] = np.floor(xv)
+                    else:
+                        lo_c[dg.nextvar] = np.ceil(xv)
+                    pc["lo"][c], pc["hi"][c], pc["ws"][c] = lo_c, hi_c, s
+            out.append(dict(slot=s, status_val=r.status_val, iter=r.iter, int_inf=dg.int_inf if ok else -1,
+                            nextvar=dg.nextvar if ok else -1, lower=r.lower if ok else np.nan,
+                            heur_viol=(-1.0 if dg.heur_feasible else 1.0) if ok else np.nan,
+                            heur_obj=dg.heur_obj if ok else np.nan))
+        return out
+
+    def pool_launch(self, chunks=1):
+        # executed eagerly; the digests stay "in flight" until a collect asks for them
+        self._pc["launched"].append([d for _ in range(chunks) for d in self._pool_chunk()])
+
+    def pool_collect(self, keep_in_flight=0):
+        pc = self._pc
+        got = []
+        while len(pc["launched"]) > keep_in_flight:
+            got.extend(pc["launched"].pop(0))
+        dt = np.dtype([("slot", "i4"), ("status_val", "i4"), ("iter", "i4"), ("int_inf", "i4"), ("nextvar", "i4"),
+                       ("reserved", "i4"), ("lower", "f8"), ("heur_viol", "f8"), ("heur_obj", "f8"), ("pri_res", "f8"),
+                       ("dua_res", "f8")])
+        arr = np.zeros(len(got), dtype=dt)
+        for k, g in enumerate(got):
+            for name in ("slot", "status_val", "iter", "int_inf", "nextvar", "lower", "heur_viol", "heur_obj"):
+                arr[k][name] = g[name]
+        active = sum(1 for c in pc["cols_state"] if c is not None)
+        return arr, active, len(pc["ring"])
