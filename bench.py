@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--batch-waves", type=int, default=6)
     ap.add_argument("--stream-warmup", type=int, default=700, help="streaming leg: chunks before the timed stretch")
     ap.add_argument("--stream-chunks", type=int, default=600, help="streaming leg: timed chunks")
+    ap.add_argument("--stream-exchange", type=int, default=4,
+                    help="streaming leg with more than one rank: chunks between two exchanges")
     ap.add_argument("--no-large-leg", action="store_true",
                     help="skip the extra BASELINE configs[4] leg (n=5000, bandwidth-bound single-node ADMM)")
     ap.add_argument("--no-probes", action="store_true",
@@ -417,52 +419,56 @@ def main():
                      device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
         waves["end_to_end_over_device"] = round(waves["node_iters_per_s"] /
                                                 max(1.0, waves["device_node_iters_per_s"] * world), 3)
-        # the stream: new MIQP, ramp-up until the columns are busy, then a timed stretch.  One rank only: the leaf
-        # pool is per GPU and the sharded search (dist.py) still deals waves, not streams -- with more ranks every
-        # rank would explore the same tree
+        # the stream: new MIQP, ramp-up until the columns are busy, then a timed stretch.  With more than one rank
+        # every rank streams its own leaf pool and the ranks meet every few chunks (dist.ShardedStream)
+        from miosqp_amd import stream as stream_mod
+        next_instance()
         if world == 1:
-            from miosqp_amd import stream as stream_mod
-            next_instance()
             ss = stream_mod.StreamSearch(model, columns=args.batch_width)
-
-            def stream_steps(count):
-                for _ in range(count):
-                    if ss.step() == 0:
-                        next_instance()
-                        ss.begin_instance()
-
-            stream_steps(args.stream_warmup)
-            sync()
-            eng.batch_stats(reset=True)
-            n2, i2, c2 = ss.nodes, ss.iters, ss.chunks
-            t2 = time.perf_counter()
-            stream_steps(args.stream_chunks)
-            eng.pool_collect(0)  # the launch in flight belongs to the timed region (its digests are not counted)
-            sync()
-            dts = time.perf_counter() - t2
-            sms, sit, snode = eng.batch_stats()
-            tots = comm.sum([ss.iters - i2, ss.nodes - n2])
-            if td is not None:
-                tb = torch.tensor([dts], dtype=torch.float64, device=comm.device)
-                td.all_reduce(tb, op=td.ReduceOp.MAX)
-                dts = float(tb.item())
-            batched = dict(width=args.batch_width, form="stream on the device-resident leaf pool",
-                           chunks=ss.chunks - c2, nodes=float(tots[1]),
-                           node_iters_per_s=round(float(tots[0]) / dts, 1), nodes_per_s=round(float(tots[1]) / dts, 2),
-                           iters_per_node=round(float(tots[0]) / max(1.0, float(tots[1])), 1),
-                           lockstep_iters=sit, device_us_per_lockstep_iter=round(1e3 * sms / max(1, sit), 2),
-                           column_occupancy=round(snode / float(max(1, args.batch_width * sit)), 3),
-                           device_node_iters_per_s=round(snode / max(1e-9, sms) * 1e3, 1),
-                           end_to_end_over_device=round(1e-3 * sms / dts, 3),
-                           open_leaves=len(ss.open), pool_slots_free=len(ss.free), dropped_at_refill=ss.dropped,
-                           waves=waves)
-            model.work.leaves = []  # the pool owns the open leaves of this instance
-            next_instance()
+            sh = None
+            stepper, restart = ss.step, ss.begin_instance
         else:
-            batched = dict(width=args.batch_width, form="waves (the streaming leaf pool is measured with one rank)",
-                           lockstep_iters=waves["lockstep_iters"],
-                           device_us_per_lockstep_iter=waves["device_us_per_lockstep_iter"],
-                           node_iters_per_s=waves["node_iters_per_s"], nodes_per_s=waves["nodes_per_s"], waves=waves)
+            sh = dist.ShardedStream(model, comm, columns=args.batch_width, exchange_every=args.stream_exchange)
+            ss = sh.ss
+            stepper, restart = sh.step, sh.begin_instance
+
+        def stream_steps(count):
+            for _ in range(count):
+                if stepper() == 0:
+                    next_instance()
+                    restart()
+
+        stream_steps(args.stream_warmup)
+        sync()
+        eng.batch_stats(reset=True)
+        n2, i2, c2 = ss.nodes, ss.iters, ss.chunks
+        t2 = time.perf_counter()
+        stream_steps(args.stream_chunks)
+        eng.pool_collect(0)  # the launch in flight belongs to the timed region (its digests are not counted)
+        sync()
+        dts = time.perf_counter() - t2
+        sms, sit, snode = eng.batch_stats()
+        tots = comm.sum([ss.iters - i2, ss.nodes - n2, sms, float(sit), float(snode), float(ss.chunks - c2)])
+        if td is not None:
+            tb = torch.tensor([dts], dtype=torch.float64, device=comm.device)
+            td.all_reduce(tb, op=td.ReduceOp.MAX)
+            dts = float(tb.item())
+        batched = dict(width=args.batch_width, form="stream on the device-resident leaf pool" +
+                       ("" if world == 1 else ", one pool per rank, incumbent + dry-rank feed every %d chunks"
+                        % args.stream_exchange),
+                       chunks=ss.chunks - c2, nodes=float(tots[1]),
+                       node_iters_per_s=round(float(tots[0]) / dts, 1), nodes_per_s=round(float(tots[1]) / dts, 2),
+                       iters_per_node=round(float(tots[0]) / max(1.0, float(tots[1])), 1),
+                       lockstep_iters=sit, device_us_per_lockstep_iter=round(1e3 * sms / max(1, sit), 2),
+                       column_occupancy=round(float(tots[4]) / float(max(1.0, args.batch_width * float(tots[3]))), 3),
+                       device_node_iters_per_s=round(float(tots[4]) / max(1e-9, float(tots[2]) / world) * 1e3, 1),
+                       end_to_end_over_device=round(1e-3 * (float(tots[2]) / world) / dts, 3),
+                       open_leaves=len(ss.open), pool_slots_free=len(ss.free), dropped_at_refill=ss.dropped,
+                       waves=waves)
+        if sh is not None:
+            batched["leaves_moved_rank0"] = sh.moved
+        model.work.leaves = []  # the pool owns the open leaves of this instance
+        next_instance()
 
     if rank == 0:
         fs = eng.factor_stats()

@@ -486,3 +486,123 @@ class ShardedSearch(object):
         w.get_return_status(finished=(self.global_open == 0 and self._open() == 0))
         w.get_return_solution()
         return waves
+
+
+class ShardedStream(object):
+    """BASELINE configs[2] across GPUs: every rank keeps its columns busy from its OWN device-resident leaf pool
+    (miosqp_amd/stream.py) and the ranks only meet every `exchange_every` chunks for the incumbent -- one all-gather
+    of (value, leaves alive, nodes, iterations) plus a broadcast of x when some rank improved it -- and, in the same
+    round, to hand leaves to ranks that ran dry (one all-gather of (alive, givable) and one broadcast per moved leaf:
+    integer-row bounds + warm start, 2 p + n + M doubles).  Every instance starts replicated like ShardedSearch:
+    all ranks expand the same first nodes (checked by `_agree`) until there are a few leaves per rank, then deal.
+    Exploration order differs from the sequential search by construction; per-node results do not."""
+
+    def __init__(self, model, comm=None, columns=256, exchange_every=4, capacity=None, ramp_leaves=4, feed=64,
+                 deal_to=None):
+        from miosqp_amd import stream
+        self.model, self.work = model, model.work
+        self.comm = comm if comm is not None else LocalComm()
+        self.seq = ShardedSearch(model, self.comm)  # replicated ramp-up (its _visit / _agree / counters)
+        self.ss = stream.StreamSearch(model, columns=columns, capacity=capacity)
+        self.exchange_every, self.ramp_leaves, self.feed = int(exchange_every), int(ramp_leaves), int(feed)
+        self.deal_to = deal_to  # None: leaves dealt round-robin; a rank: all to that one (worst case, for tests)
+        self.global_upper = np.inf
+        self.global_nodes = self.global_iters = 0
+        self.moved = 0
+        self.steps = 0
+        self._n0 = self._i0 = 0
+        self.begin_instance()
+
+    def begin_instance(self):
+        """Replicated ramp-up on the host (node at a time, identical on every rank), then the deal."""
+        w, comm, seq = self.work, self.comm, self.seq
+        if not w.leaves:
+            w.leaves = [w._make_root()]
+        seq.begin_instance()
+        rule = w.settings['tree_explor_rule']
+        target = self.ramp_leaves * comm.world
+        while 0 < len(w.leaves) < target:
+            seq._visit(rule)
+            seq._agree()
+        self.global_nodes, self.global_iters = seq.global_nodes, seq.global_iters
+        if self.deal_to is None:
+            mine = [lf for k, lf in enumerate(w.leaves) if k % comm.world == comm.rank]
+        else:
+            mine = list(w.leaves) if comm.rank == self.deal_to else []
+        self.total_alive = len(w.leaves)
+        self.global_upper = w.upper_glob
+        p = w.data.n_int
+        self.ss.begin_instance(seed_root=False)
+        for lf in mine:
+            self.ss.add_leaf(lf.l[-p:], lf.u[-p:], lf.x, lf.y, lf.depth, lf.lower)
+        self._n0, self._i0 = self.ss.nodes, self.ss.iters
+        self.steps = 0
+        w.leaves = []
+        return self.total_alive
+
+    def step(self):
+        """One chunk on this rank's stream; every `exchange_every`-th call ends with the exchange.  Returns the number
+        of leaves alive over all ranks as of the last exchange (0: the tree is closed everywhere)."""
+        alive = self.ss.step()
+        self.steps += 1
+        if self.comm.world == 1:
+            self.total_alive = alive
+            self.global_nodes += self.ss.nodes - self._n0
+            self.global_iters += self.ss.iters - self._i0
+            self._n0, self._i0 = self.ss.nodes, self.ss.iters
+            return alive
+        if self.steps % self.exchange_every == 0:
+            self.total_alive = self._exchange(alive)
+        return self.total_alive
+
+    def _exchange(self, alive):
+        w, comm, ss = self.work, self.comm, self.ss
+        extra = (ss.nodes - self._n0, ss.iters - self._i0)
+        self._n0, self._i0 = ss.nodes, ss.iters
+        best, owner, x, total = comm.exchange(w.upper_glob, w.x, alive, self.global_upper, extra)
+        self.global_nodes += int(round(comm.extra[0]))
+        self.global_iters += int(round(comm.extra[1]))
+        if x is not None:
+            self.global_upper = best
+            ss.adopt_incumbent(best, x)
+        # leaves for the ranks that ran dry: every rank derives the same plan from the gathered counts
+        tab = comm.gather([float(len(ss.open) + ss.in_flight), float(ss.givable())])
+        alive_r = [int(round(v)) for v in tab[:, 0]]
+        giv = [int(round(v)) for v in tab[:, 1]]
+        n, M, p = w.data.n, w.data.m + w.data.n_int, w.data.n_int
+        size = 2 * p + n + M + 3
+        for r in range(comm.world):
+            if alive_r[r] > 0:
+                continue
+            donor = int(np.argmax(giv))
+            count = min(self.feed, giv[donor] // 2)
+            for _ in range(count):
+                msg = None
+                if comm.rank == donor:
+                    if ss.givable() > 0:
+                        l_int, u_int, x0, y0, depth, lower = ss.give_leaf()
+                        msg = np.concatenate([l_int, u_int, x0, y0, [float(depth), float(lower), 1.0]])
+                        self.moved += 1
+                    else:  # pruned in the meantime: an empty token keeps the collective matched
+                        msg = np.zeros(size)
+                msg = comm.move(msg, size, donor)
+                if comm.rank == r and msg[-1] == 1.0:
+                    ss.add_leaf(msg[:p], msg[p:2 * p], msg[2 * p:2 * p + n], msg[2 * p + n:2 * p + n + M],
+                                int(msg[-3]), float(msg[-2]))
+            giv[donor] -= count
+            alive_r[r] += count  # (the moved leaves were counted on the donor: `total` is unchanged)
+        return total
+
+    def run(self, max_steps=10 ** 9):
+        """Until the tree is closed on every rank (or the global node budget is spent)."""
+        w = self.work
+        cap = w.settings['max_iter_bb']
+        steps = 0
+        while self.total_alive > 0 and steps < max_steps and self.global_nodes + 1 < cap:
+            self.step()
+            steps += 1
+        # every rank leaves the loop after the same exchange
+        w.osqp_iter_avg = self.global_iters / float(max(1, self.global_nodes + 1))
+        w.get_return_status(finished=self.total_alive == 0)
+        w.get_return_solution()
+        return steps

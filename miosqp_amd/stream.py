@@ -64,8 +64,9 @@ class StreamSearch(object):
         self.begin_instance()
 
     # -- instance -------------------------------------------------------------------------------
-    def begin_instance(self):
-        """(Re)starts on the model's current root: call after MIOSQP.update_vectors."""
+    def begin_instance(self, seed_root=True):
+        """(Re)starts on the model's current root: call after MIOSQP.update_vectors.  seed_root=False starts with
+        no leaf at all (the sharded search hands this rank its share through add_leaf)."""
         w = self.work
         self.eng.pool_reset()
         self._decided[:] = False
@@ -73,18 +74,53 @@ class StreamSearch(object):
         self.free = list(range(self.capacity - 1, -1, -1))  # pop() hands out slot 0 first
         self.open = []        # slots of open leaves not yet pushed, in creation order
         self.in_flight = 0    # pushed and not yet decided
-        root = w.leaves[0] if w.leaves else w._make_root()
-        s = self.free.pop()
-        self.eng.pool_write_node(s, root.l[-self.p:], root.u[-self.p:], root.x, root.y)
-        self.depth[s] = 0
-        self.lower[s] = root.lower
-        self.parent[s] = -1
-        self.kids_alive[s] = 0
-        self.open.append(s)
+        if seed_root:
+            root = w.leaves[0] if w.leaves else w._make_root()
+            self.add_leaf(root.l[-self.p:], root.u[-self.p:], root.x, root.y, 0, root.lower)
         w.leaves = []
         self.eng.pool_set_upper(w.upper_glob)
         self._launched = False
         self.active = 0
+
+    # -- leaves in and out (root, leaves dealt to or taken from this rank) ---------------------------
+    def add_leaf(self, l_int, u_int, x0, y0, depth, lower):
+        """A leaf given with explicit vectors: its integer-row bounds and its warm start."""
+        if not self.free:
+            raise MemoryError("leaf pool exhausted (raise `capacity`)")
+        s = self.free.pop()
+        self.eng.pool_write_node(s, l_int, u_int, x0, y0)
+        self.depth[s] = int(depth)
+        self.lower[s] = lower
+        self.parent[s] = -1
+        self.kids_alive[s] = 0
+        self._decided[s] = False
+        self.open.append(s)
+        return s
+
+    def givable(self):
+        """Open leaves this rank could hand to another one (not yet pushed to the device)."""
+        return len(self.open)
+
+    def give_leaf(self):
+        """Takes the shallowest open leaf out of this rank's tree (the largest subtree: keeps the receiver busy
+        longest) and returns it with explicit vectors: (l_int, u_int, x0, y0, depth, lower)."""
+        k = int(np.argmin(self.depth[np.asarray(self.open)]))
+        s = self.open.pop(k)
+        nd = self.eng.pool_read_node(s, self.p, want=("l", "u"))
+        ws = int(self.parent[s]) if self.parent[s] >= 0 else s  # its warm start: the parent's solution
+        sol = self.eng.pool_read_node(ws, self.p, want=("x", "y"))
+        rec = (nd.l, nd.u, sol.x, sol.y, int(self.depth[s]), float(self.lower[s]))
+        self._done(s)
+        return rec
+
+    def adopt_incumbent(self, value, x):
+        """An incumbent found by another rank."""
+        w = self.work
+        if value < w.upper_glob:
+            w.upper_glob = value
+            w.x = np.array(x, dtype=float)
+            self.eng.pool_set_upper(value)
+            self._prune_open()
 
     # -- slots ----------------------------------------------------------------------------------
     def _done(self, s):
@@ -218,6 +254,8 @@ class StreamSearch(object):
         alive (open on the host, waiting in the ring or being solved)."""
         if not self._launched:
             self._push(0)
+        if not self.open and self.in_flight == 0:
+            return 0  # nothing alive on this rank (it may be handed leaves later): no launch
         self.eng.pool_launch(chunks)
         self._launched = True
         self.chunks += chunks

@@ -25,6 +25,25 @@ def main():
     st = dict(problems.BNB_SETTINGS)
     model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
                 dict(problems.QP_SETTINGS))
+    if os.environ.get("MIOSQP_WORKER_MODE") == "stream":
+        # dist.ShardedStream with the CPU emulation of the leaf-pool calls (tests/digest_backend.py)
+        import digest_backend
+        model = bnb.MIOSQP(backend=digest_backend)
+        model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                    dict(st, max_iter_bb=10 ** 6), dict(problems.QP_SETTINGS))
+        s = dist.ShardedStream(model, comm, columns=4, exchange_every=per_rank, capacity=512, ramp_leaves=2, feed=4,
+                               deal_to=0)
+        s.run()
+        w = model.work
+        tot = comm.sum([s.ss.nodes, s.moved])
+        rec = dict(rank=comm.rank, upper=w.upper_glob, x=list(map(float, w.x)), status=w.status,
+                   nodes_total=float(tot[0]), moved_total=float(tot[1]), gnodes=s.global_nodes, local=s.ss.nodes,
+                   free=len(s.ss.free))
+        with open("%s.%d" % (out_path, comm.rank), "w") as f:
+            json.dump(rec, f)
+        td.barrier()
+        td.destroy_process_group()
+        return
     s = dist.ShardedSearch(model, comm)
     s.expand_until(2 * comm.world)
     before = len(model.work.leaves)

@@ -54,6 +54,33 @@ def test_two_ranks_find_the_same_optimum(tmp_path, oracle_mod, n, m, p, seed, pe
     assert recs[0]["nodes_total"] >= 1
 
 
+@pytest.mark.parametrize("every", [1, 3])
+def test_two_ranks_stream_their_own_pools(tmp_path, every):
+    """dist.ShardedStream over gloo, world_size 2, all leaves dealt to rank 0 (so rank 1 must be fed): the same
+    incumbent on both ranks, the sequential optimum, every pool slot returned."""
+    import digest_backend
+    n, m, p, seed = 50, 100, 30, 5
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MIOSQP_WORKER_MODE="stream")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(m), str(p), str(seed), str(every)]
+    subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=600)
+    recs = [json.load(open("%s.%d" % (out, r))) for r in range(2)]
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    model = bnb.MIOSQP(backend=digest_backend)
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    res = model.solve()
+    for r in recs:
+        assert r["status"] == bnb.MI_SOLVED and r["free"] == 512
+        assert r["upper"] == recs[0]["upper"] and r["gnodes"] == recs[0]["gnodes"]
+        assert abs(r["upper"] - res.upper_glob) <= 1e-3 * max(1.0, abs(res.upper_glob))
+        np.testing.assert_array_equal(np.asarray(r["x"])[pr["i_idx"]], res.x[pr["i_idx"]])
+        assert r["local"] >= 1
+    assert recs[0]["moved_total"] >= 1
+
+
 def test_local_comm_is_the_sequential_search(oracle_mod):
     pr = problems.random_miqp(20, 100, 10, seed=3)
     a = bnb.MIOSQP(backend=oracle_mod)

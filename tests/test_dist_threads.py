@@ -117,7 +117,7 @@ def test_replicated_phase_survives_a_rank_that_disagrees():
     launch was called off on that GPU).  Rank 2 is made to lose a leaf after its first replicated node: the
     all-gather of (count, checksum, incumbent) notices, everybody adopts rank 0's leaves, the deal partitions ONE
     list, no collective is left unmatched and the optimum is the sequential one."""
-    pr = problems.random_miqp(30, 150, 15, seed=4)
+    pr = problems.random_miqp(50, 100, 30, seed=5)  # ~100 nodes sequentially
     ref = bnb.MIOSQP(backend=digest_backend)
     ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
               dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
@@ -170,3 +170,38 @@ def test_global_node_budget_and_uniform_status():
     assert out[0]["status"] in (bnb.MI_MAX_ITER_FEASIBLE, bnb.MI_MAX_ITER_UNSOLVED)
     assert 11 <= out[0]["gnodes"] <= 11 + 4  # stops once the budget is reached; overshoot < one step of 4 ranks
     assert out[0]["avg"] > 0 and len(set(o["avg"] for o in out)) == 1
+
+
+@pytest.mark.parametrize("world,cols,every,deal_to", [(2, 8, 2, None), (4, 4, 3, None), (3, 16, 1, None),
+                                                      (2, 2, 1, 1), (4, 2, 2, 0)])
+def test_sharded_stream_agrees_with_the_sequential_search(world, cols, every, deal_to):
+    """dist.ShardedStream: every rank streams its own leaf pool (CPU emulation of the pool calls), the ranks meet
+    every `every` chunks for the incumbent and to feed dry ranks; all end with the same incumbent, the sequential
+    optimum, an empty tree and every pool slot returned."""
+    pr = problems.random_miqp(50, 100, 30, seed=5)  # ~100 nodes sequentially
+    ref = bnb.MIOSQP(backend=digest_backend)
+    ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+              dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    r = ref.solve()
+
+    def body(rank, comm):
+        m = bnb.MIOSQP(backend=digest_backend)
+        m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6), dict(problems.QP_SETTINGS))
+        s = dist.ShardedStream(m, comm, columns=cols, exchange_every=every, capacity=512, ramp_leaves=2, feed=4,
+                               deal_to=deal_to)
+        s.run()
+        return dict(upper=m.work.upper_glob, x=np.array(m.work.x), status=m.work.status, moved=s.moved,
+                    free=len(s.ss.free), cap=s.ss.capacity, gnodes=s.global_nodes, alive=s.total_alive,
+                    local=s.ss.nodes)
+
+    out = _threads(world, body)
+    for o in out:
+        assert o["status"] == bnb.MI_SOLVED and o["alive"] == 0 and o["free"] == o["cap"]
+        assert o["upper"] == out[0]["upper"]
+        assert abs(o["upper"] - r.upper_glob) <= 1e-3 * max(1.0, abs(r.upper_glob))
+        np.testing.assert_array_equal(o["x"][pr["i_idx"]], r.x[pr["i_idx"]])
+        assert o["gnodes"] == out[0]["gnodes"]
+    assert all(o["local"] >= 1 for o in out)  # every rank solved nodes from its own pool
+    if deal_to is not None:  # all leaves dealt to one rank: the others were fed by it
+        assert out[deal_to]["moved"] >= world - 1

@@ -1054,6 +1054,67 @@ def test_streaming_search_on_the_leaf_pool(n, m, p, seed, cols, fold):
     np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
 
 
+def test_sharded_stream_on_the_real_pool_one_rank():
+    """dist.ShardedStream with one rank (LocalComm): replicated ramp-up on the host, the leaves written into the
+    device pool with explicit vectors (add_leaf), then the stream -- the sequential optimum, every slot returned;
+    give_leaf / add_leaf round trip: a leaf taken out of the pool and put back is solved to the same result."""
+    from miosqp_amd import bnb, dist
+    pr = problems.random_miqp(50, 100, 25, seed=2)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6)
+    seq = bnb.MIOSQP()
+    seq.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS))
+    r0 = seq.solve()
+    model = bnb.MIOSQP()
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+                dict(problems.QP_SETTINGS, max_batch=64))
+    sh = dist.ShardedStream(model, columns=64, ramp_leaves=6)
+    assert sh.total_alive >= 1 and len(sh.ss.open) == sh.total_alive
+    # take every dealt leaf out and put it back: explicit vectors survive the trip through the pool
+    recs = [sh.ss.give_leaf() for _ in range(len(sh.ss.open))]
+    assert len(sh.ss.free) == sh.ss.capacity
+    for rec in recs:
+        sh.ss.add_leaf(*rec)
+    seen = []
+    sh.ss.observer = _stream_checker(pr, 1, seen)
+    # leaves put in with explicit vectors have no parent slot: the checker would use a zero warm start for them;
+    # tell it where their warm start is (their own slot)
+    own = set(int(s) for s in sh.ss.open)
+    base = sh.ss.observer
+
+    def obs(search, g):
+        if int(g["slot"]) in own:
+            return
+        base(search, g)
+    sh.ss.observer = obs
+    sh.run()
+    w = model.work
+    assert w.status == bnb.MI_SOLVED and sh.total_alive == 0 and len(sh.ss.free) == sh.ss.capacity
+    assert abs(w.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+    np.testing.assert_array_equal(w.x[pr["i_idx"]], r0.x[pr["i_idx"]])
+    assert len(seen) >= 1
+
+
+def test_two_ranks_stream_on_one_device(tmp_path):
+    """The multi-rank streaming leg of bench.py with two processes time-sharing GPU 0 (collectives over gloo,
+    MIOSQP_BENCH_ONE_DEVICE=1): exercises dist.ShardedStream against the real pool; not a performance number."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MIOSQP_BENCH_ONE_DEVICE="1")
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                         "--gpus", "2", "--steps", "20", "--warmup", "5", "--legs", "batched", "--no-probes",
+                         "--stream-warmup", "60", "--stream-chunks", "60", "--batch-width", "64",
+                         "--batch-waves", "2"],
+                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert tr.returncode == 0, tr.stderr[-3000:]
+    b = json.loads([ln for ln in tr.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    bt = b["batched"]
+    assert b["n_gpus"] == 2 and "one pool per rank" in bt["form"]
+    assert bt["nodes"] > 0 and bt["node_iters_per_s"] > 0 and 0 < bt["column_occupancy"] <= 1.0
+
+
 def test_streaming_batch_at_config3_size():
     """BASELINE config 3 as a stream: n=500, 256 columns kept full from the device-resident pool; a sample of the
     decided nodes is replayed through solve_node; the columns stay busy (no wave tail)."""
