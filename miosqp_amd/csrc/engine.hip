@@ -128,7 +128,11 @@ struct Dev {
   unsigned long long *coop_buf;  // 2 parities x N x {lo32|tag, hi32|tag}
   unsigned long long *coop_chk;  // 2 x coop_half: the test's operands [y ; x] and [proj(dy) ; dx]
   unsigned long long *coop_q;    // (256 + 16) x COOP_QS: per-workgroup, then per-group norms / sums of the test
-  unsigned long long *coop_reg;  // start-up registration counter (grows by the grid size per launch)
+  unsigned long long *coop_reg;  // start-up registration counter (grows by the grid size per launch); +64: launches with testers
+  unsigned long long *coop_chz;  // coop_half: z, the third operand of the test when it runs on tester workgroups
+  unsigned long long *coop_dec;  // the testers' decision {status | tag}
+  int coop_nt;                   // tester workgroups behind the exchange grid (0: the test runs inside the grid)
+  int coop_lag;                  // iterations between a test and the point where the grid waits for its decision
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
   int coop_dbg;                  // debug: 1 = no gather (ablation), 64 = workgroup 1 never starts (fault injection)
   int coop_nap;                  // 64-clock naps between publishing and the first poll of a round (calibrated)
@@ -454,8 +458,8 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           // the grid must fit the device with one workgroup per CU: ask the runtime instead of assuming it
           int per_cu = 0;
           const hipError_t oq = N <= 1024
-              ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 2>, 512, 0)
-              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 4>, 512, 0);
+              ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 2, true>, 512, 0)
+              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 4, true>, 512, 0);
           if (oq != hipSuccess || per_cu < 1) can = false;
         }
         if (wantc && can) {
@@ -473,7 +477,18 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_chk, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_q, (size_t)(256 + 16) * COOP_QS + 64);
-          if (!rc) rc = dalloc(e, &d.coop_reg, 64);
+          if (!rc) rc = dalloc(e, &d.coop_reg, 128);
+          if (!rc) rc = dalloc(e, &d.coop_chz, d.coop_half + 64);
+          if (!rc) rc = dalloc(e, &d.coop_dec, 64);
+          {
+            // the test on workgroups of its own when the exchange grid leaves enough CUs free
+            const int spare = prop.multiProcessorCount - T;
+            int nt = spare >= 8 ? std::min(COOP_NT_MAX, spare) : 0;
+            if (const char *ev = getenv("MIOSQP_COOP_TESTERS")) nt = std::max(0, std::min(std::min(COOP_NT_MAX, spare), atoi(ev)));
+            d.coop_nt = nt;
+            d.coop_lag = 12;
+            if (const char *ev = getenv("MIOSQP_COOP_LAG")) d.coop_lag = std::max(1, atoi(ev));
+          }
           double *Kc = nullptr;
           if (!rc) rc = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
           const bool timing = getenv("MIOSQP_SETUP_TIMING") != nullptr;
@@ -848,7 +863,7 @@ int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z
       HIPCHK(hipMemcpyAsync(e->h_ctrl, e->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
       if (e->h_ctrl->pad == 1) {  // called off, iterates untouched: the same k iterations in the two-kernel form
-        (void)hipMemsetAsync(e->d.coop_reg, 0, 64 * sizeof(unsigned long long), e->stream);
+        (void)hipMemsetAsync(e->d.coop_reg, 0, 128 * sizeof(unsigned long long), e->stream);
         g_err = "cooperative solver: the grid was not co-resident within 100 ms (device shared?), stage 1";
         int rc = leave_coop(e);
         if (rc) return rc;
