@@ -259,6 +259,9 @@ def main():
                     help="with more than one rank a step is 'node relaxations for this long, at least one' "
                          "instead of a fixed count (ranks then meet at the exchange without waiting for the "
                          "rank that drew the expensive node); -1 = 0.5 + 0.5 log2(ranks) ms, 0 = fixed count (--wave)")
+    ap.add_argument("--python-loop", action="store_true",
+                    help="headline: drive every node from Python (solve_node + bnb.Workspace, vectors over PCIe) instead "
+                         "of the C++ host loop on device-resident leaves (miosqp_qp_search_*)")
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg5"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -333,17 +336,18 @@ def main():
     rng = np.random.RandomState(args.seed + 12345)
     stream = dict(instances=1, closed=[])  # closed: (time, global nodes of that tree) per closed tree
 
-    def next_instance():
+    def next_instance(who=None):
         """The tree closed: re-root on the next MIQP of the stream.  Same P and A, hence the same
         factor in HBM; new q, l, u drawn like the generator draws them (run_example.py:76-80), pushed
         through MIOSQP.update_vectors exactly like the reference's MPC loop does
         (/root/reference/miosqp/solver.py:174-205).  Every rank draws the same numbers."""
-        stream["closed"].append((time.perf_counter(), srch.global_nodes))
+        who = srch if who is None else who
+        stream["closed"].append((time.perf_counter(), who.global_nodes))
         q = rng.randn(cfg["n"])
         u = 2 + rng.rand(m_orig)
         l = -2 + rng.rand(m_orig)
         model.update_vectors(q=q, l=l, u=u)
-        srch.begin_instance()
+        who.begin_instance()
         stream["instances"] += 1
 
     def sync():
@@ -360,19 +364,64 @@ def main():
             if srch.step(width, batched, budget=None if batched else budget) == 0:
                 next_instance()
 
-    run_steps(args.warmup, args.wave, False)
+    # the headline: node-at-a-time branch and bound.  The loop runs in the C++ host library on device-resident leaves
+    # (miosqp_amd/search.py); with more than one rank every rank runs it on its share of the tree and the ranks meet
+    # after every step for the incumbent (dist.ShardedStream).  --python-loop: the same search driven from Python.
+    hosted = hasattr(eng, "search_create") and not args.python_loop
+
+    class Head(object):
+        """what the timed loop needs of either form"""
+        def __init__(self):
+            from miosqp_amd import search
+            self.hs = search.HostedSearch(model)
+            self.sh = None
+            if world > 1:
+                self.sh = dist.ShardedStream(model, comm, search=self.hs, exchange_every=1,
+                                             step_kwargs=dict(nodes=10 ** 9 if budget else args.wave, budget=budget))
+            self._g0 = 0
+
+        nodes = property(lambda self: self.hs.nodes)
+        iters = property(lambda self: self.hs.iters)
+        global_nodes = property(lambda self: self.sh.global_nodes if self.sh else self.hs.nodes - self._g0)
+
+        def step(self):
+            return self.sh.step() if self.sh else self.hs.step(args.wave)
+
+        def begin_instance(self):
+            self._g0 = self.hs.nodes
+            return self.sh.begin_instance() if self.sh else self.hs.begin_instance()
+
+        def drain(self):
+            pass
+
+    if hosted:
+        head = Head()
+
+        def head_steps(count):
+            for _ in range(count):
+                if head.step() == 0:
+                    next_instance(head)
+    else:
+        head = srch
+
+        def head_steps(count):
+            run_steps(count, args.wave, False)
+
+    head_steps(args.warmup)
     sync()
     eng.loop_stats(reset=True)
-    n0, i0, inst0 = srch.nodes, srch.iters, stream["instances"]
+    n0, i0, inst0 = head.nodes, head.iters, stream["instances"]
     del stream["closed"][:]
     t0 = time.perf_counter()
-    run_steps(args.steps, args.wave, False)
-    srch.drain()  # the exchange still in flight belongs to the timed region
+    head_steps(args.steps)
+    head.drain()  # the exchange still in flight belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
     loop_ms, loop_iters = eng.loop_stats()
-    nodes_here = srch.nodes - n0
-    tot = comm.sum([srch.iters - i0, srch.nodes - n0, dt])
+    nodes_here = head.nodes - n0
+    tot = comm.sum([head.iters - i0, head.nodes - n0, dt])
+    if hosted:
+        model.work.leaves = []  # the open leaves of this instance live in device slots
     dt_max = dt
     if td is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm.device)
@@ -535,6 +584,8 @@ def main():
                                else "L (4 launches/iteration)",
                                qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3),
                                coop_fallbacks=fs["coop_fallbacks"], replicated_resyncs=srch.resyncs,
+                               host_loop="C++ host library on device-resident leaves (miosqp_qp_search_*)" if hosted
+                               else "Python (bnb.Workspace driving miosqp_qp_solve_node)",
                                comm=type(comm).__name__ + ("/nccl" if (td is not None and not one_dev) else "")),
                    roofline=roof)
         out["config"]["instances_in_timed_region"] = instances

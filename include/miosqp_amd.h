@@ -39,6 +39,7 @@ extern "C" {
 #define MIOSQP_EFACTOR (-3)   /* KKT factorisation broke down (non-convex P?) */
 #define MIOSQP_ENODEV (-4)    /* no usable gfx950 device */
 #define MIOSQP_EUNSUPPORTED (-5) /* the entry point does not cover this problem size / engine form (caller falls back) */
+#define MIOSQP_EFULL (-6)     /* the leaf store of miosqp_qp_search_* has no free slot (raise the capacity) */
 #define MIOSQP_EBOUNDS 1      /* update_bounds: some l[i] > u[i]; nothing was changed */
 
 /* Solver parameters = the keyword arguments the reference forwards verbatim to
@@ -170,6 +171,43 @@ typedef struct miosqp_tree_info {
 int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, const double *x0, const double *y0,
                          double upper0, const double *x_inc0, int32_t tree_explor_rule, int32_t max_iter_bb,
                          double *x_out, miosqp_tree_info *info);
+
+/* ---- node-at-a-time branch and bound, driven from the host in C++ -------------------------------------
+ * The loop of /root/reference/miosqp/solver.py:65-172 (choose_leaf -> Node.solve -> bound_and_branch, workspace.py:
+ * 113-155, 274-334) for problems of any size, one relaxation at a time in whatever form the engine uses for single
+ * nodes.  The open leaves are device slots (integer-row bounds + solution = the children's warm start), the children
+ * are written on the device (workspace.py:157-203), a node's outcome reaches the host as a 96-byte record: no vector
+ * crosses PCIe per node and no interpreter runs between two nodes.  Same list semantics as the Python mirror
+ * (creation order, first maximum, the prune traversal of workspace.py:278-280); the heuristic incumbent's value is
+ * the device's.  Needs set_integer_rows + set_root. */
+typedef struct miosqp_search_info {
+  int64_t nodes;        /* nodes solved in this call */
+  int64_t osqp_iter;    /* ADMM iterations over them */
+  int32_t open_leaves;  /* leaves still open (0: the tree is closed) */
+  int32_t free_slots;
+  int32_t improved;     /* 1: the incumbent improved in this call */
+  int32_t reserved;
+  double upper_glob, lower_glob;
+  double device_time;   /* seconds inside the ADMM loops of these nodes (device events) */
+  double run_time;
+} miosqp_search_info;
+
+int miosqp_qp_search_create(miosqp_qp_engine *e, int32_t capacity);
+/* new MIQP on the same factor: no leaves, no incumbent */
+int miosqp_qp_search_reset(miosqp_qp_engine *e);
+/* appends a leaf given with explicit vectors (the root, or one from another rank): l_int, u_int (n_int), x0 (n), y0 (M) */
+int miosqp_qp_search_add_leaf(miosqp_qp_engine *e, const double *l_int, const double *u_int, const double *x0,
+                              const double *y0, int32_t depth, double lower);
+/* removes the shallowest open leaf and returns it with explicit vectors; 1 when there is none */
+int miosqp_qp_search_take_leaf(miosqp_qp_engine *e, double *l_int, double *u_int, double *x0, double *y0,
+                               int32_t *depth, double *lower);
+/* adopts an incumbent from outside when it is better (MIOSQP.set_x0, another rank) and prunes against it */
+int miosqp_qp_search_set_incumbent(miosqp_qp_engine *e, double upper, const double *x);
+/* *upper >= 1.7e308: none yet (x untouched) */
+int miosqp_qp_search_get_incumbent(miosqp_qp_engine *e, double *upper, double *x);
+/* solves nodes until the list is empty, max_nodes are done or budget_s seconds have passed (<= 0: no time limit) */
+int miosqp_qp_search_run(miosqp_qp_engine *e, int32_t tree_explor_rule, int64_t max_nodes, double budget_s,
+                         miosqp_search_info *info);
 
 /* ---- device-resident leaf pool + streaming batch -------------------------------------------------------
  * Workspace.leaves and child generation (/root/reference/miosqp/workspace.py:83,

@@ -36,6 +36,12 @@ class TreeInfo(C.Structure):
                 ("device_time", C.c_double), ("run_time", C.c_double)]
 
 
+class SearchInfo(C.Structure):
+    _fields_ = [("nodes", C.c_int64), ("osqp_iter", C.c_int64), ("open_leaves", C.c_int32), ("free_slots", C.c_int32),
+                ("improved", C.c_int32), ("reserved", C.c_int32), ("upper_glob", C.c_double), ("lower_glob", C.c_double),
+                ("device_time", C.c_double), ("run_time", C.c_double)]
+
+
 class PoolDigest(C.Structure):
     _fields_ = [("slot", C.c_int32), ("status_val", C.c_int32), ("iter", C.c_int32), ("int_inf", C.c_int32),
                 ("nextvar", C.c_int32), ("reserved", C.c_int32), ("lower", C.c_double), ("heur_viol", C.c_double),
@@ -55,6 +61,13 @@ SYMBOLS = {
     "miosqp_qp_set_integer_rows": (C.c_int, [C.c_void_p, C.c_int32, ip, C.c_int32]),
     "miosqp_qp_set_root": (C.c_int, [C.c_void_p, dp, dp, C.c_double, C.c_double]),
     "miosqp_qp_solve_node": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, C.POINTER(Info)]),
+    "miosqp_qp_search_create": (C.c_int, [C.c_void_p, C.c_int32]),
+    "miosqp_qp_search_reset": (C.c_int, [C.c_void_p]),
+    "miosqp_qp_search_add_leaf": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.c_int32, C.c_double]),
+    "miosqp_qp_search_take_leaf": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "miosqp_qp_search_set_incumbent": (C.c_int, [C.c_void_p, C.c_double, dp]),
+    "miosqp_qp_search_get_incumbent": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), dp]),
+    "miosqp_qp_search_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.POINTER(SearchInfo)]),
     "miosqp_qp_solve_batch": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp,
                                         C.POINTER(Info)]),
     "miosqp_qp_solve_tree": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.c_double, dp, C.c_int32, C.c_int32, dp,

@@ -463,7 +463,8 @@ class MIOSQP(object):
         the root and reads the outcome.  Falls through to the host loop when the engine does not cover the problem
         (too large, no device digest) or the leaf list overflowed.  settings['device_tree'] = False keeps the host loop."""
         st = work.settings
-        if not st.get('device_tree', True) or not hasattr(work.solver, 'solve_tree') or getattr(work, '_no_tree', False):
+        if not hasattr(work.solver, 'solve_tree') or getattr(work, '_no_tree', False) or not st.get('device_tree', True):
+            self._solve_hosted(work)
             return
         if st['branching_rule'] != 0 or st['tree_explor_rule'] not in (0, 1) or len(work.leaves) != 1 \
                 or work.iter_num != 1 or work.data.n_int == 0 or 'eps_abs' not in work.qp_settings \
@@ -475,6 +476,7 @@ class MIOSQP(object):
                                    st['tree_explor_rule'], st['max_iter_bb'])
         if r is None:
             work._no_tree = True  # this engine form never will: do not ask again
+            self._solve_hosted(work)
             return
         if r.info.overflow:
             return  # more leaves alive than the launch holds: the host loop redoes the search from the root
@@ -489,6 +491,29 @@ class MIOSQP(object):
         work.leaves = [] if r.info.leaves_left == 0 else [root] * int(r.info.leaves_left)
         if work.leaves:
             work.iter_num = max(work.iter_num, st['max_iter_bb'])
+
+    def _solve_hosted(self, work):
+        """Larger problems: the same loop in the C++ host library with the leaves in device slots
+        (`miosqp_qp_search_*`, miosqp_amd/search.py) -- no interpreter and no vector traffic between two nodes.
+        settings['device_search'] = False keeps the Python loop."""
+        st = work.settings
+        if not st.get('device_search', True) or not hasattr(work.solver, 'search_create'):
+            return
+        if st['branching_rule'] != 0 or st['tree_explor_rule'] not in (0, 1) or len(work.leaves) != 1 \
+                or work.iter_num != 1 or work.data.n_int == 0 or 'eps_abs' not in work.qp_settings \
+                or not st.get('device_digest', True):
+            return
+        from miosqp_amd import search
+        hs = getattr(work, '_hosted', None)
+        root = work.leaves[0]
+        if hs is None:
+            hs = work._hosted = search.HostedSearch(self)
+        else:
+            hs.begin_instance()
+        alive = hs._open
+        while alive > 0 and work.iter_num < st['max_iter_bb']:
+            alive = hs.step(st['max_iter_bb'] - work.iter_num)
+        work.leaves = [root] * int(alive)  # the leaves live on the device; what matters is whether any is left
 
     def update_vectors(self, q=None, l=None, u=None):
         # solver.py:174-205: same factorisation, new root, statistics reset

@@ -188,6 +188,7 @@ struct Dev {
 #include "kernels_pool.inc"  // device-resident leaf pool, streaming batch (refill / harvest between chunks)
 #include "host.inc"  // host side: engine object, allocation, launches, graph capture, solve loops
 #include "host_pool.inc"  // host side of the leaf pool (C ABI miosqp_qp_pool_*)
+#include "host_search.inc"  // node-at-a-time branch and bound driven from the host in C++ (C ABI miosqp_qp_search_*)
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -241,6 +242,11 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   drop_stream_graph(e);
   for (hipEvent_t ev : e->ev_pool)
     if (ev) hipEventDestroy(ev);
+  if (e->search) {
+    NodeSearch *S = static_cast<NodeSearch *>(e->search);
+    if (S->dg) hipHostFree(S->dg);
+    delete S;
+  }
   if (e->h_ready) hipHostFree(e->h_ready);
   if (e->h_dg) hipHostFree(e->h_dg);
   if (e->h_pctl) hipHostFree(e->h_pctl);

@@ -498,12 +498,16 @@ class ShardedStream(object):
     Exploration order differs from the sequential search by construction; per-node results do not."""
 
     def __init__(self, model, comm=None, columns=256, exchange_every=4, capacity=None, ramp_leaves=4, feed=64,
-                 deal_to=None):
+                 deal_to=None, search=None, step_kwargs=None):
+        """search: the per-rank search object when it is not a StreamSearch on the leaf pool -- anything with its
+        interface, e.g. search.HostedSearch (node-at-a-time relaxations, loop in the C++ library); step_kwargs: what
+        its step() is called with (HostedSearch: nodes=, budget=)."""
         from miosqp_amd import stream
         self.model, self.work = model, model.work
         self.comm = comm if comm is not None else LocalComm()
         self.seq = ShardedSearch(model, self.comm)  # replicated ramp-up (its _visit / _agree / counters)
-        self.ss = stream.StreamSearch(model, columns=columns, capacity=capacity)
+        self.ss = search if search is not None else stream.StreamSearch(model, columns=columns, capacity=capacity)
+        self.step_kwargs = dict(step_kwargs or {})
         self.exchange_every, self.ramp_leaves, self.feed = int(exchange_every), int(ramp_leaves), int(feed)
         self.deal_to = deal_to  # None: leaves dealt round-robin; a rank: all to that one (worst case, for tests)
         self.global_upper = np.inf
@@ -543,7 +547,7 @@ class ShardedStream(object):
     def step(self):
         """One chunk on this rank's stream; every `exchange_every`-th call ends with the exchange.  Returns the number
         of leaves alive over all ranks as of the last exchange (0: the tree is closed everywhere)."""
-        alive = self.ss.step()
+        alive = self.ss.step(**self.step_kwargs)
         self.steps += 1
         if self.comm.world == 1:
             self.total_alive = alive

@@ -207,6 +207,47 @@ class OSQP(object):
             raise ValueError("Lower bound must be lower than or equal to upper bound")
         return types.SimpleNamespace(x=x, info=info)
 
+    # -- node-at-a-time branch and bound driven from the host in C++ (miosqp_qp_search_*) --------------
+    def search_create(self, capacity):
+        _check(self._lib.miosqp_qp_search_create(self._h, int(capacity)), "search_create")
+        self._search_info = _lib.SearchInfo()
+
+    def search_reset(self):
+        _check(self._lib.miosqp_qp_search_reset(self._h), "search_reset")
+
+    def search_add_leaf(self, l_int, u_int, x0, y0, depth, lower):
+        k = len(l_int)
+        rc = _check(self._lib.miosqp_qp_search_add_leaf(
+            self._h, _lib.as_d(_f64(l_int, k, "l_int")), _lib.as_d(_f64(u_int, k, "u_int")),
+            _lib.as_d(_f64(x0, self.n, "x0")), _lib.as_d(_f64(y0, self.m, "y0")), int(depth), float(lower)),
+            "search_add_leaf")
+        if rc == 1:
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+
+    def search_take_leaf(self, n_int):
+        """(l_int, u_int, x0, y0, depth, lower) of the shallowest open leaf, removed from the list; None if none."""
+        l, u, x, y = np.empty(n_int), np.empty(n_int), np.empty(self.n), np.empty(self.m)
+        depth, lower = C.c_int32(), C.c_double()
+        rc = _check(self._lib.miosqp_qp_search_take_leaf(self._h, _lib.as_d(l), _lib.as_d(u), _lib.as_d(x), _lib.as_d(y),
+                                                         C.byref(depth), C.byref(lower)), "search_take_leaf")
+        return None if rc == 1 else (l, u, x, y, depth.value, lower.value)
+
+    def search_set_incumbent(self, upper, x):
+        _check(self._lib.miosqp_qp_search_set_incumbent(self._h, float(upper), _lib.as_d(_f64(x, self.n, "x"))),
+               "search_set_incumbent")
+
+    def search_get_incumbent(self):
+        """(upper, x); x is None while there is no incumbent."""
+        upper, x = C.c_double(), np.empty(self.n)
+        _check(self._lib.miosqp_qp_search_get_incumbent(self._h, C.byref(upper), _lib.as_d(x)), "search_get_incumbent")
+        return (upper.value, x) if upper.value < 1.7e308 else (float("inf"), None)
+
+    def search_run(self, tree_explor_rule, max_nodes, budget_s=0.0):
+        info = self._search_info
+        _check(self._lib.miosqp_qp_search_run(self._h, int(tree_explor_rule), int(max_nodes), float(budget_s),
+                                              C.byref(info)), "search_run")
+        return info
+
     # -- device-resident leaf pool + streaming batch (miosqp_qp_pool_*) ------------------------------
     POOL_PRUNED = -100
 

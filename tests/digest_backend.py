@@ -165,3 +165,91 @@ class OSQP(oracle.OSQP):
                 arr[k][name] = g[name]
         active = sum(1 for c in pc["cols_state"] if c is not None)
         return arr, active, len(pc["ring"])
+
+    # ---- CPU emulation of the hosted node-at-a-time search (miosqp_qp_search_*, csrc/host_search.inc): the same
+    #      list semantics (creation order, first maximum, prune traversal) on solve_node above.  Test infrastructure.
+    def search_create(self, capacity):
+        self._sc = dict(cap=int(capacity))
+        self.search_reset()
+
+    def search_reset(self):
+        self._sc.update(open=[], upper=np.inf, inc=None, used=0)
+
+    def search_add_leaf(self, l_int, u_int, x0, y0, depth, lower):
+        if np.any(np.asarray(l_int) > np.asarray(u_int)):
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+        self._sc["open"].append(dict(l=np.array(l_int, dtype=float), u=np.array(u_int, dtype=float),
+                                     x=np.array(x0, dtype=float), y=np.array(y0, dtype=float), depth=int(depth),
+                                     lower=float(lower)))
+
+    def search_take_leaf(self, n_int):
+        op = self._sc["open"]
+        if not op:
+            return None
+        k = int(np.argmin([lf["depth"] for lf in op]))
+        lf = op.pop(k)
+        return lf["l"], lf["u"], lf["x"], lf["y"], lf["depth"], lf["lower"]
+
+    def _search_prune(self):
+        sc, k = self._sc, 0
+        while k < len(sc["open"]):
+            if sc["open"][k]["lower"] > sc["upper"]:
+                del sc["open"][k]
+            k += 1
+
+    def search_set_incumbent(self, upper, x):
+        sc = self._sc
+        if upper < sc["upper"]:
+            sc["upper"], sc["inc"] = float(upper), np.array(x, dtype=float)
+            self._search_prune()
+
+    def search_get_incumbent(self):
+        sc = self._sc
+        return (sc["upper"], None if sc["inc"] is None else sc["inc"].copy())
+
+    def search_run(self, tree_explor_rule, max_nodes, budget_s=0.0):
+        import time
+        sc, t0 = self._sc, time.perf_counter()
+        lr, ur = self._root[0], self._root[1]
+        m, done, iters, improved = self._m, 0, 0, 0
+        while sc["open"] and done < max_nodes:
+            if budget_s > 0 and done > 0 and time.perf_counter() - t0 >= budget_s:
+                break
+            op = sc["open"]
+            if tree_explor_rule == 0 or not np.isfinite(sc["upper"]):
+                k = int(np.argmax([lf["depth"] for lf in op]))
+            else:
+                k = int(np.argmax([lf["lower"] for lf in op]))
+            lf = op.pop(k)
+            l, u = lr.copy(), ur.copy()
+            l[m:], u[m:] = lf["l"], lf["u"]
+            r = self.solve_node(l, u, lf["x"], lf["y"])
+            done += 1
+            iters += int(r.iter)
+            if r.status_val not in (1, -2):
+                continue
+            lower = float(r.lower)
+            if lower > sc["upper"]:
+                continue
+            dg = r.digest
+            if dg.int_inf == 0:
+                sc["upper"], sc["inc"], improved = lower, r.x.copy(), 1
+                self._search_prune()
+                continue
+            if dg.heur_feasible and dg.heur_obj < sc["upper"]:
+                xr = r.x.copy()
+                xr[self._ii] = np.round(xr[self._ii])
+                sc["upper"], sc["inc"], improved = float(dg.heur_obj), xr, 1
+                self._search_prune()
+            xv = r.x[self._ii[dg.nextvar]]
+            for side in (0, 1):
+                cl, cu = lf["l"].copy(), lf["u"].copy()
+                if side == 0:
+                    cu[dg.nextvar] = np.floor(xv)
+                else:
+                    cl[dg.nextvar] = np.ceil(xv)
+                op.append(dict(l=cl, u=cu, x=r.x, y=r.y, depth=lf["depth"] + 1, lower=lower))
+        lg = min([lf["lower"] for lf in sc["open"]]) if sc["open"] else sc["upper"]
+        return types.SimpleNamespace(nodes=done, osqp_iter=iters, open_leaves=len(sc["open"]),
+                                     free_slots=sc["cap"] - len(sc["open"]), improved=improved, upper_glob=sc["upper"],
+                                     lower_glob=lg, device_time=0.0, run_time=time.perf_counter() - t0)

@@ -1115,6 +1115,103 @@ def test_two_ranks_stream_on_one_device(tmp_path):
     assert bt["nodes"] > 0 and bt["node_iters_per_s"] > 0 and 0 < bt["column_occupancy"] <= 1.0
 
 
+@pytest.mark.parametrize("n,m,p,seed,rule", [(30, 150, 15, 4, 1), (50, 100, 25, 2, 1), (20, 40, 10, 1, 0), (100, 150, 40, 7, 1),
+                                              (60, 120, 60, 3, 0)])
+def test_hosted_search_equals_the_python_loop(n, m, p, seed, rule):
+    """miosqp_qp_search_* (the loop of solver.py:65-172 in the C++ host library, leaves in device slots, children
+    written on the device): same nodes, same ADMM iterations, same incumbent as the Python loop driving solve_node;
+    a second MIQP on the same factor; leaves taken out and put back; an incumbent handed in from outside."""
+    from miosqp_amd import bnb, search
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    st = dict(problems.BNB_SETTINGS, tree_explor_rule=rule)
+    qs = dict(problems.QP_SETTINGS, resident=0)  # (small problems would otherwise run as one launch: kernels_tree.inc)
+    py = bnb.MIOSQP()
+    py.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+             dict(st, device_search=False, device_tree=False), dict(qs))
+    cc = bnb.MIOSQP()
+    cc.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st, device_tree=False), dict(qs))
+    ii = pr["i_idx"]
+    rng = np.random.RandomState(seed)
+    for inst in range(2):
+        r0, r1 = py.solve(), cc.solve()
+        assert getattr(cc.work, "_hosted", None) is not None and getattr(py.work, "_hosted", None) is None
+        assert r1.status == r0.status
+        assert (cc.work.iter_num, cc.work.osqp_iter) == (py.work.iter_num, py.work.osqp_iter)
+        if r0.status == bnb.MI_SOLVED:
+            assert abs(r1.upper_glob - r0.upper_glob) <= 1e-9 * max(1.0, abs(r0.upper_glob))
+            np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
+            assert rel(r1.x, r0.x) <= SOL_TOL
+        assert len(cc.work._hosted.free) == cc.work._hosted.capacity  # every slot came back
+        q2 = rng.randn(n)
+        py.update_vectors(q=q2)
+        cc.update_vectors(q=q2)
+    # leaves out and in again, stepping node by node; an incumbent from outside prunes
+    hs = cc.work._hosted
+    hs.begin_instance()
+    for _ in range(6):
+        if hs.step(1) == 0:
+            break
+    if hs.givable() >= 2:
+        recs = [hs.give_leaf() for _ in range(hs.givable())]
+        assert hs.givable() == 0
+        for rec in recs:
+            hs.add_leaf(*rec)
+        assert hs.givable() == len(recs)
+    r2 = hs.run()
+    r0 = py.solve()
+    assert r2.status == r0.status
+    if r0.status == bnb.MI_SOLVED:
+        assert abs(r2.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+        np.testing.assert_array_equal(r2.x[ii], r0.x[ii])
+        # the optimum handed in before the search starts: nothing better is found, the tree closes sooner
+        cc.update_vectors(q=q2)
+        cc.work.upper_glob, cc.work.x = r0.upper_glob - 1e-6, r0.x.copy()
+        hs.begin_instance()
+        r3 = hs.run()
+        assert r3.upper_glob == r0.upper_glob - 1e-6 and cc.work.iter_num <= py.work.iter_num
+
+
+def test_hosted_search_at_config2_size():
+    """Config 2 (n=500, m=1000, p=250) through the hosted search in the engine's cooperative form: the first 40 nodes
+    equal the Python loop's (nodes, iterations, incumbent)."""
+    from miosqp_amd import bnb
+    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=41)
+    out = []
+    for hosted in (False, True):
+        mdl = bnb.MIOSQP()
+        mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                  dict(st, device_search=hosted), dict(problems.QP_SETTINGS))
+        r = mdl.solve()
+        assert (getattr(mdl.work, "_hosted", None) is not None) == hosted
+        out.append((r.status, mdl.work.iter_num, mdl.work.osqp_iter, r.upper_glob, mdl.work.solver.factor_stats()["coop"]))
+    assert out[0][:3] == out[1][:3] and out[1][4]
+    if np.isfinite(out[0][3]):
+        assert abs(out[0][3] - out[1][3]) <= 1e-9 * max(1.0, abs(out[0][3]))
+
+
+def test_sharded_hosted_search_one_rank():
+    """dist.ShardedStream over search.HostedSearch (node-at-a-time per rank): ramp-up on the host, deal, hosted
+    steps with a node budget, closes with the sequential optimum."""
+    from miosqp_amd import bnb, dist, search
+    pr = problems.random_miqp(50, 100, 25, seed=2)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6)
+    seq = bnb.MIOSQP()
+    seq.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st, device_search=False),
+              dict(problems.QP_SETTINGS, resident=0))
+    r0 = seq.solve()
+    model = bnb.MIOSQP()
+    model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+                dict(problems.QP_SETTINGS, resident=0))
+    hs = search.HostedSearch(model)
+    sh = dist.ShardedStream(model, search=hs, step_kwargs=dict(nodes=3), ramp_leaves=4)
+    sh.run()
+    w = model.work
+    assert w.status == bnb.MI_SOLVED and sh.total_alive == 0 and len(hs.free) == hs.capacity
+    assert abs(w.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+    np.testing.assert_array_equal(w.x[pr["i_idx"]], r0.x[pr["i_idx"]])
+
+
 def test_streaming_batch_at_config3_size():
     """BASELINE config 3 as a stream: n=500, 256 columns kept full from the device-resident pool; a sample of the
     decided nodes is replayed through solve_node; the columns stay busy (no wave tail)."""
