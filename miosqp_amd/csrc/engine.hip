@@ -549,28 +549,44 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   return 0;
 }
 
+// The update / warm-start calls return as soon as their work is queued (the solve that follows is ordered behind it
+// on the engine's stream); what must not happen is the NEXT upload overwriting the pinned staging area while the
+// previous copy out of it is still under way: one event per staging region, waited for before the region is rewritten.
+static int stage_wait(miosqp_qp_engine *e, int k) {
+  if (e->stage_busy[k]) {
+    HIPCHK(hipEventSynchronize(e->rt.ev_stage[k]));
+    e->stage_busy[k] = false;
+  }
+  return 0;
+}
+static int stage_mark(miosqp_qp_engine *e, int k) {
+  HIPCHK(hipEventRecord(e->rt.ev_stage[k], e->stream));
+  e->stage_busy[k] = true;
+  return 0;
+}
+
 int miosqp_qp_update_bounds(miosqp_qp_engine *e, const double *l, const double *u) {
   if (!e || !l || !u) return MIOSQP_EARG;
   ENTER(e);
   for (int i = 0; i < e->M; i++)
     if (l[i] > u[i]) return MIOSQP_EBOUNDS;
+  if (int rc = stage_wait(e, 0)) return rc;
   memcpy(e->h_in, l, sizeof(double) * e->M);
   memcpy(e->h_in + e->M, u, sizeof(double) * e->M);
   HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * 2 * e->M, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_scale_bounds, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, e->d);
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return 0;
+  return stage_mark(e, 0);
 }
 
 int miosqp_qp_update_lin_cost(miosqp_qp_engine *e, const double *q) {
   if (!e || !q) return MIOSQP_EARG;
   ENTER(e);
+  if (int rc = stage_wait(e, 1)) return rc;
   double *hx = e->h_in + 2 * (size_t)e->M;
   memcpy(hx, q, sizeof(double) * e->n);
   HIPCHK(hipMemcpyAsync(e->d.raw_x, hx, sizeof(double) * e->n, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_scale_q, dim3((e->n + 255) / 256), dim3(256), 0, e->stream, e->d);
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return 0;
+  return stage_mark(e, 1);
 }
 
 static int enqueue_warm(miosqp_qp_engine *e) {
@@ -583,13 +599,13 @@ static int enqueue_warm(miosqp_qp_engine *e) {
 int miosqp_qp_warm_start(miosqp_qp_engine *e, const double *x, const double *y) {
   if (!e || !x || !y) return MIOSQP_EARG;
   ENTER(e);
+  if (int rc = stage_wait(e, 1)) return rc;
   double *hx = e->h_in + 2 * (size_t)e->M;
   memcpy(hx, x, sizeof(double) * e->n);
   memcpy(hx + e->n, y, sizeof(double) * e->M);
   HIPCHK(hipMemcpyAsync(e->d.raw_x, hx, sizeof(double) * (e->n + e->M), hipMemcpyHostToDevice, e->stream));
   enqueue_warm(e);
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return 0;
+  return stage_mark(e, 1);
 }
 
 static int begin_solve(miosqp_qp_engine *e) {
@@ -710,6 +726,8 @@ int miosqp_qp_solve_node(miosqp_qp_engine *e, const double *l, const double *u, 
   const int n = e->n, M = e->M;
   for (int i = 0; i < M; i++)
     if (l[i] > u[i]) return MIOSQP_EBOUNDS;
+  if (int rcw = stage_wait(e, 0)) return rcw;
+  if (int rcw = stage_wait(e, 1)) return rcw;
   memcpy(e->h_in, l, sizeof(double) * M);
   memcpy(e->h_in + M, u, sizeof(double) * M);
   memcpy(e->h_in + 2 * (size_t)M, x0, sizeof(double) * n);
@@ -799,6 +817,8 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     if (rc) return rc;
     e->tree_ready = true;
   }
+  if (int rcw = stage_wait(e, 0)) return rcw;
+  if (int rcw = stage_wait(e, 1)) return rcw;
   memcpy(e->h_in, l, sizeof(double) * M);
   memcpy(e->h_in + M, u, sizeof(double) * M);
   memcpy(e->h_in + 2 * (size_t)M, x0, sizeof(double) * n);

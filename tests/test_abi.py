@@ -67,3 +67,20 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# tests pass the CPU oracle", "").lower() or \
                     f in ("bnb.py",), (dirpath, f)
+
+
+def test_cooperative_exchange_loop_has_no_register_spills():
+    """tools/check_coop_isa.py: the exchange loop of every k_coop instantiation (inline-asm loads whose completion the
+    compiler cannot see) must not touch scratch -- a spill between such a load and its s_waitcnt would store a register
+    whose data has not arrived.  Compiles the device code to assembly (hipcc cross-compiles here, ~15 s)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        import pytest
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_coop_isa.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("scratch accesses 0") >= 4
