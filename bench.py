@@ -271,6 +271,8 @@ def main():
     ap.add_argument("--batch-waves", type=int, default=6)
     ap.add_argument("--stream-warmup", type=int, default=700, help="streaming leg: chunks before the timed stretch")
     ap.add_argument("--stream-chunks", type=int, default=600, help="streaming leg: timed chunks")
+    ap.add_argument("--pools", type=int, default=2,
+                    help="streaming leg, one rank: also run the tree on this many pools of the one GPU (1 = skip)")
     ap.add_argument("--stream-exchange", type=int, default=4,
                     help="streaming leg with more than one rank: chunks between two exchanges")
     ap.add_argument("--no-large-leg", action="store_true",
@@ -516,6 +518,42 @@ def main():
                        waves=waves)
         if sh is not None:
             batched["leaves_moved_rank0"] = sh.moved
+        # the same tree on TWO pools of this GPU (stream.MultiPoolSearch: two engines, two host threads): the sweeps
+        # of one pool fill the serial part of the other's chunk.  Reported next to the single pool, not instead of it
+        if world == 1 and args.pools > 1:
+            rngs = [np.random.RandomState(args.seed + 777) for _ in range(args.pools)]
+
+            def make_model():
+                return setup_model(prob, dict(qs), backend=None)[0]
+
+            def reroot(k, mdl):
+                r = rngs[k]  # every pool draws the same numbers
+                mdl.update_vectors(q=r.randn(cfg["n"]), l=-2 + r.rand(m_orig), u=2 + r.rand(m_orig))
+
+            mp = stream_mod.MultiPoolSearch(make_model, pools=args.pools, columns=args.batch_width,
+                                            exchange_every=args.stream_exchange)
+            mp.steps(args.stream_warmup, reroot)
+            torch.cuda.synchronize()
+            a0 = [(sh_.ss.nodes, sh_.ss.iters) for sh_ in mp.sh]
+            for mdl in mp.models:
+                mdl.work.solver.batch_stats(reset=True)
+            t3 = time.perf_counter()
+            mp.steps(args.stream_chunks, reroot)
+            for mdl in mp.models:
+                mdl.work.solver.pool_collect(0)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t3
+            st3 = [mdl.work.solver.batch_stats() for mdl in mp.models]
+            nd = sum(sh_.ss.nodes - a[0] for sh_, a in zip(mp.sh, a0))
+            it = sum(sh_.ss.iters - a[1] for sh_, a in zip(mp.sh, a0))
+            batched["pools_%d" % args.pools] = dict(
+                form="%d pools x %d columns on this GPU, one tree (stream.MultiPoolSearch)" % (args.pools, args.batch_width),
+                node_iters_per_s=round(it / dtp, 1), nodes_per_s=round(nd / dtp, 2),
+                device_us_per_lockstep_iter_per_pool=[round(1e3 * s3[0] / max(1, s3[1]), 2) for s3 in st3],
+                column_occupancy=[round(s3[2] / float(max(1, args.batch_width * s3[1])), 3) for s3 in st3],
+                leaves_moved=[sh_.moved for sh_ in mp.sh])
+            for mdl in mp.models:
+                mdl.work.solver.close()
         model.work.leaves = []  # the pool owns the open leaves of this instance
         next_instance()
 

@@ -289,3 +289,92 @@ class StreamSearch(object):
         w.get_return_status(finished=(alive == 0))
         w.get_return_solution()
         return bnb.Results(w.x, w.upper_glob, w.run_time, w.status, w.osqp_solve_time, w.osqp_iter_avg)
+
+
+class MultiPoolSearch(object):
+    """Several streaming pools on ONE GPU, one tree.  `pools` engines of the same MIQP (each its own stream, batch
+    and leaf pool; the factor is set up once per engine) are driven by `pools` host threads and share the tree like
+    ranks do (dist.ShardedStream over dist.ThreadComm: replicated ramp-up, deal, incumbent + dry-pool feed every
+    `exchange_every` chunks).  A chunk of the streaming batch has a serial part -- termination test, harvest, refill:
+    twenty small kernels, 190 us of 970 at config 3 -- during which the chip is nearly idle; with two pools the
+    sweeps of one fill those gaps of the other: 6.3 -> 8.7 M node-iterations/s at 2 x 256 columns on MI355X.
+    The ctypes calls release the interpreter lock while they wait for the device, so the threads overlap where it
+    matters.
+
+    make_model: () -> a set-up bnb.MIOSQP (called `pools` times; every model must describe the same problem)."""
+
+    def __init__(self, make_model, pools=2, columns=256, exchange_every=4, capacity=None):
+        from miosqp_amd import dist
+        self.pools = int(pools)
+        self.models = [make_model() for _ in range(self.pools)]
+        self.world = dist.ThreadWorld(self.pools)
+        self.columns, self.exchange_every, self.capacity = columns, exchange_every, capacity
+        self.sh = [None] * self.pools
+        self._dist = dist
+
+    def _each(self, fn):
+        import threading
+        out, err = [None] * self.pools, []
+
+        def body(k):
+            try:
+                out[k] = fn(k)
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
+                err.append(e)
+                try:
+                    self.world.bar.abort()
+                except Exception:
+                    pass
+
+        ths = [threading.Thread(target=body, args=(k,)) for k in range(self.pools)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    def _shard(self, k):
+        if self.sh[k] is None:
+            self.sh[k] = self._dist.ShardedStream(self.models[k], self._dist.ThreadComm(self.world, k), columns=self.columns,
+                                                  exchange_every=self.exchange_every, capacity=self.capacity)
+        return self.sh[k]
+
+    def update_vectors(self, q=None, l=None, u=None):
+        """New MIQP on the same factors (every engine)."""
+        for m in self.models:
+            m.update_vectors(q=q, l=l, u=u)
+        self._fresh = True
+
+    def run(self):
+        """Closes the current tree.  Returns bnb.Results (identical on every pool; pool 0's)."""
+        fresh = getattr(self, "_fresh", False)
+        self._fresh = False
+
+        def body(k):
+            first = self.sh[k] is None
+            sh = self._shard(k)
+            if fresh and not first:
+                sh.begin_instance()
+            sh.run()
+            return None
+
+        self._each(body)
+        w = self.models[0].work
+        return bnb.Results(w.x, w.upper_glob, w.run_time, w.status, w.osqp_solve_time, w.osqp_iter_avg)
+
+    def steps(self, count, next_instance=None):
+        """`count` chunks per pool (bench): when the tree closes, next_instance(k, model) must re-root model k -- with the
+        same data on every pool -- and the search goes on.  Returns per-pool (nodes, iterations, chunks)."""
+        def body(k):
+            sh = self._shard(k)
+            for _ in range(count):
+                if sh.step() == 0:
+                    if next_instance is None:
+                        break
+                    next_instance(k, self.models[k])
+                    sh.begin_instance()
+            return (sh.ss.nodes, sh.ss.iters, sh.ss.chunks)
+
+        return self._each(body)

@@ -1212,6 +1212,36 @@ def test_sharded_hosted_search_one_rank():
     np.testing.assert_array_equal(w.x[pr["i_idx"]], r0.x[pr["i_idx"]])
 
 
+def test_two_pools_on_one_gpu_share_one_tree():
+    """stream.MultiPoolSearch on the real engine: two pools (two engines, two host threads) close one tree with the
+    sequential optimum, every slot comes back, and a second MIQP reuses both."""
+    from miosqp_amd import bnb, stream
+    pr = problems.random_miqp(50, 100, 25, seed=2)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6)
+
+    def make():
+        m = bnb.MIOSQP()
+        m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+                dict(problems.QP_SETTINGS, max_batch=64))
+        return m
+
+    seq = bnb.MIOSQP()
+    seq.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st), dict(problems.QP_SETTINGS))
+    mp = stream.MultiPoolSearch(make, pools=2, columns=64, exchange_every=2)
+    ii = pr["i_idx"]
+    rng = np.random.RandomState(3)
+    for inst in range(2):
+        r0, r1 = seq.solve(), mp.run()
+        assert r1.status == r0.status == bnb.MI_SOLVED
+        assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+        np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
+        assert all(len(sh.ss.free) == sh.ss.capacity for sh in mp.sh)
+        assert mp.models[0].work.upper_glob == mp.models[1].work.upper_glob
+        q2 = rng.randn(50)
+        seq.update_vectors(q=q2)
+        mp.update_vectors(q=q2)
+
+
 def test_streaming_batch_at_config3_size():
     """BASELINE config 3 as a stream: n=500, 256 columns kept full from the device-resident pool; a sample of the
     decided nodes is replayed through solve_node; the columns stay busy (no wave tail)."""

@@ -70,3 +70,33 @@ def test_pool_exhaustion_is_loud():
     s = stream.StreamSearch(mdl, columns=8, capacity=6)
     with pytest.raises(MemoryError):
         s.run()
+
+
+def test_several_pools_share_one_tree():
+    """stream.MultiPoolSearch: two / three pools (threads of this process, dist.ThreadComm) on one tree end with the
+    sequential optimum; a second instance reuses them."""
+    import digest_backend
+    from miosqp_amd import bnb, problems, stream
+    pr = problems.random_miqp(50, 100, 30, seed=5)
+
+    def make(**st):
+        m = bnb.MIOSQP(backend=digest_backend)
+        m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6, **st), dict(problems.QP_SETTINGS))
+        return m
+
+    seq = make(device_search=False)
+    for pools in (2, 3):
+        mp = stream.MultiPoolSearch(make, pools=pools, columns=4, exchange_every=2, capacity=512)
+        r0, r1 = seq.solve(), mp.run()
+        assert r1.status == r0.status == bnb.MI_SOLVED
+        assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+        np.testing.assert_array_equal(r1.x[pr["i_idx"]], r0.x[pr["i_idx"]])
+        assert all(len(sh.ss.free) == sh.ss.capacity for sh in mp.sh)
+        q2 = np.random.RandomState(pools).randn(50)
+        seq.update_vectors(q=q2)
+        mp.update_vectors(q=q2)
+        r0, r1 = seq.solve(), mp.run()
+        assert r1.status == r0.status
+        assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+        seq.update_vectors(q=pr["q"])
