@@ -377,7 +377,7 @@ def main():
             from miosqp_amd import search
             self.hs = search.HostedSearch(model)
             self.sh = None
-            if world > 1:
+            if world > 1 or (launched and os.environ.get("MIOSQP_FORCE_EXCHANGE") == "1"):
                 self.sh = dist.ShardedStream(model, comm, search=self.hs, exchange_every=1,
                                              step_kwargs=dict(nodes=10 ** 9 if budget else args.wave, budget=budget))
             self._g0 = 0

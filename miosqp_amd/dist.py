@@ -14,6 +14,8 @@ Per-node results are identical to single-GPU mode (a node is a pure function of 
 visiting order differs from the reference's one-at-a-time order, so node counts can differ
 (SURVEY.md sec. 8e "parity caveat").
 """
+import os
+
 import numpy as np
 
 
@@ -594,6 +596,9 @@ class ShardedStream(object):
         self.seq = ShardedSearch(model, self.comm)  # replicated ramp-up (its _visit / _agree / counters)
         self.ss = search if search is not None else stream.StreamSearch(model, columns=columns, capacity=capacity)
         self.step_kwargs = dict(step_kwargs or {})
+        # MIOSQP_FORCE_EXCHANGE=1: the exchange runs although there is one rank (first contact with a new
+        # communicator: `torch.distributed.run --nproc-per-node 1` exercises every collective used below)
+        self.force_exchange = os.environ.get("MIOSQP_FORCE_EXCHANGE") == "1"
         self.exchange_every, self.ramp_leaves, self.feed = int(exchange_every), int(ramp_leaves), int(feed)
         self.deal_to = deal_to  # None: leaves dealt round-robin; a rank: all to that one (worst case, for tests)
         self.global_upper = np.inf
@@ -635,7 +640,7 @@ class ShardedStream(object):
         of leaves alive over all ranks as of the last exchange (0: the tree is closed everywhere)."""
         alive = self.ss.step(**self.step_kwargs)
         self.steps += 1
-        if self.comm.world == 1:
+        if self.comm.world == 1 and not self.force_exchange:
             self.total_alive = alive
             self.global_nodes += self.ss.nodes - self._n0
             self.global_iters += self.ss.iters - self._i0

@@ -944,8 +944,11 @@ def test_single_rank_torchrun_goes_through_rccl(tmp_path):
     assert tr.returncode == 0, tr.stderr[-2000:]
     b = json.loads([ln for ln in tr.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert a["config"]["comm"] == "LocalComm" and b["config"]["comm"] == "TorchComm/nccl"
-    assert (a["nodes"], a["iters_per_node"]) == (b["nodes"], b["iters_per_node"])
-    assert 0.6 * a["value"] <= b["value"] <= 1.4 * a["value"]
+    # the forced exchange runs the sharded form (replicated ramp-up, deal, all-gathers every step): the same number of
+    # nodes per step, another visiting order
+    assert a["nodes"] == b["nodes"]
+    assert 0.5 * a["iters_per_node"] <= b["iters_per_node"] <= 2.0 * a["iters_per_node"]
+    assert 0.5 * a["value"] <= b["value"] <= 1.5 * a["value"]
     assert b["n_gpus"] == 1 and b["roofline"]["kernel"] == a["roofline"]["kernel"]
 
 
