@@ -13,6 +13,8 @@
 
 #include <cstdio>
 
+#include "factor.hpp"  // DenseAccelCtx
+
 namespace {
 
 constexpr int NB = 64, LP = NB + 1;  // tile size, padded LDS row
@@ -210,14 +212,16 @@ __global__ __launch_bounds__(256) void ks_out(const double *X, double *Linv, dou
 
 // matches miosqp::DenseLdlInv (factor.hpp)
 int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double *Linv, double *LinvT, void *ctx) {
-  hipStream_t st = (hipStream_t)ctx;
+  miosqp::DenseAccelCtx *actx = static_cast<miosqp::DenseAccelCtx *>(ctx);
+  hipStream_t st = actx ? (hipStream_t)actx->stream : nullptr;
+  const bool keep = actx && actx->keep_on_device;
   double *dS = nullptr, *dX = nullptr, *dT = nullptr, *dW = nullptr, *dd = nullptr;
   int *dflag = nullptr, hflag = 0, rc = 0;
   const size_t mat = (size_t)n * ld * sizeof(double);
   const int nt = (n + NB - 1) / NB;
-  SCK(hipMalloc((void **)&dS, mat));
+  SCK(hipMalloc((void **)&dS, mat + 64 * sizeof(double)));  // (+64: the engine's tile loads may overshoot a row)
   SCK(hipMalloc((void **)&dX, mat));
-  SCK(hipMalloc((void **)&dT, mat));
+  SCK(hipMalloc((void **)&dT, mat + 64 * sizeof(double)));
   SCK(hipMalloc((void **)&dW, (size_t)n * NB * sizeof(double)));
   SCK(hipMalloc((void **)&dd, (size_t)n * sizeof(double)));
   SCK(hipMalloc((void **)&dflag, sizeof(int)));
@@ -243,13 +247,20 @@ int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double 
   // dS is free now: reuse it for Linv
   hipLaunchKernelGGL(ks_out, dim3(nt, nt), dim3(256), 0, st, dX, dS, dT, ld, n);
   SCK(hipMemcpyAsync(d, dd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-  SCK(hipMemcpyAsync(Linv, dS, mat, hipMemcpyDeviceToHost, st));
-  SCK(hipMemcpyAsync(LinvT, dT, mat, hipMemcpyDeviceToHost, st));
+  if (!keep) {
+    SCK(hipMemcpyAsync(Linv, dS, mat, hipMemcpyDeviceToHost, st));
+    SCK(hipMemcpyAsync(LinvT, dT, mat, hipMemcpyDeviceToHost, st));
+  }
   SCK(hipStreamSynchronize(st));
+  if (keep) {  // the caller owns them from here on
+    actx->dLinv = dS;
+    actx->dLinvT = dT;
+    dS = dT = nullptr;
+  }
 done:
-  hipFree(dS);
+  if (dS) hipFree(dS);
   hipFree(dX);
-  hipFree(dT);
+  if (dT) hipFree(dT);
   hipFree(dW);
   hipFree(dd);
   hipFree(dflag);

@@ -313,12 +313,36 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   int on_dev = s->setup_on_device;
   if (on_dev < 0) on_dev = n >= 1024 ? 1 : 0;
   e->setup_on_device = on_dev != 0;
+  // Will the product form be built (on the host, from Linv)?  Decided here because the device stage of the setup may
+  // then leave Linv / LinvT on the device instead of sending them down and up again.
+  int want_fold = s->fold;
+  bool coop_pref = false;
+  {
+    const double dens = M > 0 ? (double)Ap[n] / ((double)n * M) : 0.0;
+    const double fold_bytes = 8.0 * ((double)n * (M + n) + (double)M * n);
+    const bool fits_lds = resident_lds_doubles(n, M) * sizeof(double) <= 150 * 1024;
+    // the cooperative solver only needs the product form to build its explicit inverse from, whatever
+    // the sparsity; it is preferred from n + M = 64 on (measured: equal to the LDS-resident workgroup
+    // below 100, 1.8x at 160, 2.2x at 240)
+    int coop_req = s->coop;
+    if (const char *ev = getenv("MIOSQP_COOP")) coop_req = atoi(ev);
+    const bool coop_fits = M > 0 && n + M <= 2048;
+    coop_pref = coop_fits && (coop_req == 1 || (coop_req < 0 && n + M >= 64)) && s->resident != 1;
+    if (want_fold < 0)
+      want_fold = (M > 0 && ((dens >= 0.30 && fold_bytes <= 4.0e9) || (fits_lds && s->resident != 0) || coop_pref)) ? 1 : 0;
+  }
+  miosqp::DenseAccelCtx actx;
+  actx.keep_on_device = on_dev && !(want_fold && M > 0) && !getenv("MIOSQP_SETUP_ROUNDTRIP");
   if (!miosqp::build_factor(e->sc, Pp, Pi, Px, s->rho, s->sigma, e->fa, err,
-                            on_dev ? miosqp_device_ldl_inverse : nullptr, nullptr)) {
+                            on_dev ? miosqp_device_ldl_inverse : nullptr, &actx)) {
     g_err = err;
+    if (actx.dLinv) hipFree(actx.dLinv);
+    if (actx.dLinvT) hipFree(actx.dLinvT);
     delete e;
     return MIOSQP_EFACTOR;
   }
+  if (actx.dLinv) e->allocs.push_back(actx.dLinv);    // freed with the engine
+  if (actx.dLinvT) e->allocs.push_back(actx.dLinvT);
   tick("host: scaling + factor (total)");
   e->nnzA = Ap[n];
   e->nnzPtriu = (int64_t)e->sc.Pi.size();
@@ -344,7 +368,13 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   } while (0)
   UP(f.panel_by_var.ptr, pv_ptr); UP(f.panel_by_var.idx, pv_idx); UP(f.panel_by_var.val, pv_L); UP(f.At_val, pv_At);
   UP(f.panel_by_con.ptr, pc_ptr); UP(f.panel_by_con.idx, pc_idx); UP(f.panel_by_con.val, pc_L); UP(f.A_val, pc_A);
-  UP(f.Linv, Linv); UP(f.LinvT, LinvT); UP(f.d2inv, d2inv);
+  if (actx.dLinv) {  // computed on the device and left there
+    d.Linv = actx.dLinv;
+    d.LinvT = actx.dLinvT;
+  } else {
+    UP(f.Linv, Linv); UP(f.LinvT, LinvT);
+  }
+  UP(f.d2inv, d2inv);
   UP(f.Pbar.ptr, pb_ptr); UP(f.Pbar.idx, pb_idx); UP(f.Pbar.val, pb_val);
   UP(f.Praw.ptr, pr_ptr); UP(f.Praw.idx, pr_idx); UP(f.Praw.val, pr_val);
   UP(e->sc.D, D); UP(e->sc.Dinv, Dinv); UP(e->sc.E, E); UP(e->sc.Einv, Einv);
@@ -397,20 +427,8 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->tpr_pb = pick_tpr((double)f.Pbar.nnz / n);
   e->tpr_pr = pick_tpr((double)f.Praw.nnz / n);
   {
-    // product-form factor: worth it when the panel is dense (bytes no worse, half the launches)
-    const double dens = M > 0 ? (double)f.nnz_panel / ((double)n * M) : 0.0;
-    const double fold_bytes = 8.0 * ((double)n * (M + n) + (double)M * n);
-    int want = s->fold;
-    const bool fits_lds = resident_lds_doubles(n, M) * sizeof(double) <= 150 * 1024;
-    // the cooperative solver only needs the product form to build its explicit inverse from, whatever
-    // the sparsity; it is preferred from n + M = 64 on (measured: equal to the LDS-resident workgroup
-    // below 100, 1.8x at 160, 2.2x at 240)
-    int coop_req = s->coop;
-    if (const char *ev = getenv("MIOSQP_COOP")) coop_req = atoi(ev);
-    const bool coop_fits = M > 0 && n + M <= 2048;
-    const bool coop_pref = coop_fits && (coop_req == 1 || (coop_req < 0 && n + M >= 64)) && s->resident != 1;
-    if (want < 0)
-      want = (M > 0 && ((dens >= 0.30 && fold_bytes <= 4.0e9) || (fits_lds && s->resident != 0) || coop_pref)) ? 1 : 0;
+    // product-form factor: worth it when the panel is dense (bytes no worse, half the launches); decided above
+    const int want = want_fold;
     if (want && M > 0) {
       miosqp::build_folded(f, e->fo);
       int rc = dupload(e, e->fo.rows, &d.f_rows);

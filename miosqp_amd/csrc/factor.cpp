@@ -5,7 +5,10 @@
 #include <atomic>
 #include <cmath>
 #include <functional>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
+#include <pthread.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,25 +36,105 @@ inline double clamp_scaling(double v) {
   return v;
 }
 
-// dynamic-chunk parallel loop over [0, count)
+// dynamic-chunk parallel loop over [0, count).  The workers are created once per process and reused: a setup at
+// config 5 runs ~80 of these loops, and spawning 32 threads for each cost more than the loops themselves (60 of the
+// 85 ms of the equilibration).  One loop at a time (a mutex serialises concurrent setups); a loop started from inside a
+// worker runs serially.
+class WorkerPool {
+ public:
+  static WorkerPool &get() {
+    static WorkerPool p;
+    return p;
+  }
+  int size() const { return (int)workers_.size(); }
+  void run(int64_t count, const std::function<void(int64_t)> &fn) {
+    if (workers_.empty() || in_worker() || forked().load()) {  // (a forked child has no workers: serial)
+      for (int64_t i = 0; i < count; i++) fn(i);
+      return;
+    }
+    std::lock_guard<std::mutex> region(region_);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      count_ = count;
+      next_.store(0);
+      busy_ = (int)workers_.size();
+      epoch_++;
+    }
+    cv_.notify_all();
+    work();  // the caller takes chunks too
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return busy_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  static std::atomic<bool> &forked() {
+    static std::atomic<bool> f{false};
+    return f;
+  }
+  WorkerPool() {
+    pthread_atfork(nullptr, nullptr, []() { forked().store(true); });
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::min<unsigned>(hw ? hw : 1, 32);
+    for (int t = 0; t + 1 < nthreads; t++)
+      workers_.emplace_back([this]() {
+        flag() = true;
+        uint64_t seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+            if (stop_) return;
+            seen = epoch_;
+          }
+          work();
+          std::lock_guard<std::mutex> lk(m_);
+          if (--busy_ == 0) done_.notify_all();
+        }
+      });
+  }
+  ~WorkerPool() {
+    if (forked().load()) {  // the threads do not exist in this process
+      for (auto &th : workers_) th.detach();
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &th : workers_) th.join();
+  }
+  static bool &flag() {
+    static thread_local bool f = false;
+    return f;
+  }
+  static bool in_worker() { return flag(); }
+  void work() {
+    for (;;) {
+      const int64_t i = next_.fetch_add(1);
+      if (i >= count_) break;
+      (*fn_)(i);
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_, region_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int64_t)> *fn_ = nullptr;
+  int64_t count_ = 0;
+  std::atomic<int64_t> next_{0};
+  int busy_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+
 void parallel_chunks(int64_t count, int64_t work_per_item, const std::function<void(int64_t)> &fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  int nthreads = (int)std::min<int64_t>(hw ? hw : 1, 32);
-  if (nthreads <= 1 || count < 2 || count * work_per_item < (int64_t)1 << 22) {
+  if (count < 2 || count * work_per_item < (int64_t)1 << 22) {
     for (int64_t i = 0; i < count; i++) fn(i);
     return;
   }
-  std::atomic<int64_t> next(0);
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nthreads; t++)
-    pool.emplace_back([&]() {
-      for (;;) {
-        int64_t i = next.fetch_add(1);
-        if (i >= count) break;
-        fn(i);
-      }
-    });
-  for (auto &th : pool) th.join();
+  WorkerPool::get().run(count, fn);
 }
 
 // contiguous column ranges [lo, hi) for the parallel loops of the equilibration (max and element-wise
@@ -244,39 +327,71 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
   tm.lap("panel rows");
   // ---- symmetric matrices by row (counting transpose of the upper triangle; columns ascend) ----
   {
+    // Row r of the full symmetric matrix = [column r of the upper triangle: entries (i, r), i <= r, as columns i]
+    // followed by [row r of the strict upper triangle: entries (r, j), j > r] -- both ascending, so the row comes out
+    // sorted.  The first part is copied per row; the second is a transpose of the strict upper triangle done in
+    // kColChunks column chunks with per-chunk histograms and cursors (no atomics, the result does not depend on the
+    // number of threads).
     auto sym_rows = [&](const int *Pp_, const int *Pi_, const double *Px_, bool upper_only_input, PCsr &out) {
-      out.rows = out.cols = n;
-      std::vector<int> cnt(n, 0);
-      for (int j = 0; j < n; j++)
-        for (int p = Pp_[j]; p < Pp_[j + 1]; p++) {
-          const int i = Pi_[p];
-          if (i > j) continue;  // only the upper triangle is read
-          cnt[i]++;
-          if (i != j) cnt[j]++;
-        }
       (void)upper_only_input;
+      out.rows = out.cols = n;
+      const int64_t nnz_in = Pp_[n];
+      std::vector<int> colcnt(n, 0);                           // entries of column r with i <= r
+      std::vector<int> hist((size_t)kColChunks * n, 0);        // [chunk][row]: strict upper entries of that row in the chunk
+      parallel_chunks(kColChunks, nnz_in / kColChunks + 1, [&](int64_t c) {
+        int lo, hi;
+        col_range(n, c, lo, hi);
+        int *h = &hist[(size_t)c * n];
+        for (int j = lo; j < hi; j++) {
+          int cc = 0;
+          for (int p = Pp_[j]; p < Pp_[j + 1]; p++) {
+            const int i = Pi_[p];
+            if (i > j) continue;  // only the upper triangle is read
+            cc++;
+            if (i != j) h[i]++;
+          }
+          colcnt[j] = cc;
+        }
+      });
       out.ptr.assign(n + 1, 0);
       out.nnz = 0;
+      std::vector<int> cnt(n);
       for (int i = 0; i < n; i++) {
-        out.nnz += cnt[i];
-        out.ptr[i + 1] = out.ptr[i] + ((cnt[i] + 1) & ~1);
+        int c2 = colcnt[i];
+        for (int c = 0; c < kColChunks; c++) {
+          const int v = hist[(size_t)c * n + i];
+          hist[(size_t)c * n + i] = c2;  // becomes the chunk's cursor inside row i
+          c2 += v;
+        }
+        cnt[i] = c2;
+        out.nnz += c2;
+        out.ptr[i + 1] = out.ptr[i] + ((c2 + 1) & ~1);
       }
       out.idx.assign(out.ptr[n], 0);
       out.val.assign(out.ptr[n], 0.0);
-      std::vector<int> cur(out.ptr.begin(), out.ptr.end() - 1);
-      for (int j = 0; j < n; j++)
-        for (int p = Pp_[j]; p < Pp_[j + 1]; p++) {
-          const int i = Pi_[p];
-          if (i > j) continue;
-          out.idx[cur[i]] = j;
-          out.val[cur[i]++] = Px_[p];
-          if (i != j) {
-            out.idx[cur[j]] = i;
-            out.val[cur[j]++] = Px_[p];
+      parallel_chunks(kColChunks, nnz_in / kColChunks + 1, [&](int64_t c) {
+        int lo, hi;
+        col_range(n, c, lo, hi);
+        int *cur = &hist[(size_t)c * n];
+        for (int j = lo; j < hi; j++) {
+          int w = out.ptr[j];  // first part of row j: its own column
+          for (int p = Pp_[j]; p < Pp_[j + 1]; p++) {
+            const int i = Pi_[p];
+            if (i > j) continue;
+            out.idx[w] = i;
+            out.val[w++] = Px_[p];
+            if (i != j) {  // second part of row i
+              const int q = out.ptr[i] + cur[i]++;
+              out.idx[q] = j;
+              out.val[q] = Px_[p];
+            }
           }
         }
-      for (int i = 0; i < n; i++)
-        if (cur[i] < out.ptr[i + 1]) out.idx[cur[i]] = cnt[i] ? out.idx[cur[i] - 1] : 0;  // zero-valued pad
+      });
+      for (int i = 0; i < n; i++) {
+        const int e = out.ptr[i] + cnt[i];
+        if (e < out.ptr[i + 1]) out.idx[e] = cnt[i] ? out.idx[e - 1] : 0;  // zero-valued pad
+      }
     };
     sym_rows(s.Pp.data(), s.Pi.data(), s.Px.data(), true, f.Pbar);
     sym_rows(Pp_raw, Pi_raw, Px_raw, false, f.Praw);
@@ -310,9 +425,16 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
   if (accel) {
     // dense LDL^T, triangular inverse and transpose on the device
     std::vector<double> dd(n);
-    f.Linv.assign((size_t)n * ld, 0.0);
-    f.LinvT.assign((size_t)n * ld, 0.0);
-    const int rc = accel(n, ld, S.data(), dd.data(), f.Linv.data(), f.LinvT.data(), accel_ctx);
+    const DenseAccelCtx *actx = static_cast<const DenseAccelCtx *>(accel_ctx);
+    const bool keep = actx && actx->keep_on_device;
+    f.Linv.clear();
+    f.LinvT.clear();
+    if (!keep) {
+      f.Linv.assign((size_t)n * ld, 0.0);
+      f.LinvT.assign((size_t)n * ld, 0.0);
+    }
+    const int rc = accel(n, ld, S.data(), dd.data(), keep ? nullptr : f.Linv.data(), keep ? nullptr : f.LinvT.data(),
+                         accel_ctx);
     if (rc == 1) {
       err = "KKT factorisation: non-positive pivot in the reduced Hessian (P not PSD?)";
       return false;

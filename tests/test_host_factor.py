@@ -179,5 +179,14 @@ def test_equilibration_of_a_large_matrix_takes_the_threaded_path(hh, oracle_mod)
         np.testing.assert_allclose(D, Do, rtol=1e-14)
         np.testing.assert_allclose(E, Eo, rtol=1e-14)
         assert abs(c.value - co) <= 1e-14 * co
+        # the symmetric matrices by row (threaded transpose of the upper triangle: per-chunk histograms and cursors)
+        x, v = rng.randn(n), rng.randn(M)
+        Ax, Atv, Px, Prx = np.empty(M), np.empty(n), np.empty(n), np.empty(n)
+        hh.hh_products(h, _d(x), _d(v), _d(Ax), _d(Atv), _d(Px), _d(Prx))
+        Pd = P.toarray()
+        np.testing.assert_allclose(Prx, Pd @ x, rtol=0, atol=1e-10 * np.abs(Pd @ x).max())
+        Pb = c.value * (D[:, None] * Pd * D[None, :])
+        np.testing.assert_allclose(Px, Pb @ x, rtol=0, atol=1e-10 * np.abs(Pb @ x).max())
+        assert hh.hh_layout_ok(h)
     finally:
         hh.hh_free(h)
