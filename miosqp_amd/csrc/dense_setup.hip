@@ -208,6 +208,41 @@ __global__ __launch_bounds__(256) void ks_out(const double *X, double *Linv, dou
   }
 }
 
+// Row i1 of S = Pbar + sigma I + rho Abar^T Abar (lower triangle; the rest of the row is written as zeros) by ONE
+// workgroup, accumulated in LDS in exactly the host's order (factor.cpp): the row starts as Pbar's entries, then sigma
+// on the diagonal, then for every constraint row r that holds variable i1 (ascending) w = rho Abar[r][i1] times row r
+// of Abar up to column i1, one fused multiply-add per entry.  Entries of one constraint row are distinct columns
+// (the zero-valued pad that repeats the last column is skipped: it adds nothing), so the lanes never collide; a
+// barrier separates consecutive constraint rows.
+__global__ __launch_bounds__(256) void ks_schur_row(double *__restrict__ S, int ld, int n, double rho, double sigma,
+                                                    const int *__restrict__ Pp, const int *__restrict__ Pi,
+                                                    const double *__restrict__ Px, const int *__restrict__ Ap,
+                                                    const int *__restrict__ Ai, const double *__restrict__ Ax,
+                                                    const int *__restrict__ Rptr, const int *__restrict__ Ridx,
+                                                    const double *__restrict__ Rval) {
+  extern __shared__ double acc[];
+  const int i1 = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < ld; c += 256) acc[c] = 0.0;
+  __syncthreads();
+  for (int p = Pp[i1] + tid; p < Pp[i1 + 1]; p += 256) acc[Pi[p]] += Px[p];  // (i <= i1, distinct)
+  __syncthreads();
+  if (tid == 0) acc[i1] += sigma;
+  __syncthreads();
+  for (int p = Ap[i1]; p < Ap[i1 + 1]; p++) {
+    const int r = Ai[p];
+    const double w = rho * Ax[p];
+    const int k0 = Rptr[r], k1 = Rptr[r + 1];
+    for (int k = k0 + tid; k < k1; k += 256) {
+      const int i2 = Ridx[k];
+      if (i2 > i1) continue;
+      if (k > k0 && Ridx[k - 1] == i2) continue;  // the pad
+      acc[i2] = fma(w, Rval[k], acc[i2]);
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < ld; c += 256) S[(size_t)i1 * ld + c] = acc[c];
+}
+
 }  // namespace
 
 // matches miosqp::DenseLdlInv (factor.hpp)
@@ -216,6 +251,7 @@ int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double 
   hipStream_t st = actx ? (hipStream_t)actx->stream : nullptr;
   const bool keep = actx && actx->keep_on_device;
   double *dS = nullptr, *dX = nullptr, *dT = nullptr, *dW = nullptr, *dd = nullptr;
+  char *dIn = nullptr;
   int *dflag = nullptr, hflag = 0, rc = 0;
   const size_t mat = (size_t)n * ld * sizeof(double);
   const int nt = (n + NB - 1) / NB;
@@ -225,7 +261,28 @@ int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double 
   SCK(hipMalloc((void **)&dW, (size_t)n * NB * sizeof(double)));
   SCK(hipMalloc((void **)&dd, (size_t)n * sizeof(double)));
   SCK(hipMalloc((void **)&dflag, sizeof(int)));
-  SCK(hipMemcpyAsync(dS, S, mat, hipMemcpyHostToDevice, st));
+  if (S) {
+    SCK(hipMemcpyAsync(dS, S, mat, hipMemcpyHostToDevice, st));
+  } else {
+    // S assembled here from the scaled matrices (factor.hpp: schur_on_device)
+    if (!actx || !actx->schur_on_device) { rc = -2; goto done; }
+    const size_t bi = sizeof(int), bd = sizeof(double);
+    const size_t sizes[9] = {(size_t)(n + 1) * bi, (size_t)actx->nnzP * bi, (size_t)actx->nnzP * bd, (size_t)(n + 1) * bi,
+                             (size_t)actx->nnzA * bi, (size_t)actx->nnzA * bd, (size_t)(actx->M + 1) * bi,
+                             (size_t)actx->nnzR * bi, (size_t)actx->nnzR * bd};
+    const void *src[9] = {actx->Pp, actx->Pi, actx->Px, actx->Ap, actx->Ai, actx->Ax, actx->Rptr, actx->Ridx, actx->Rval};
+    size_t off[10];
+    off[0] = 0;
+    for (int k = 0; k < 9; k++) off[k + 1] = off[k] + ((sizes[k] + 255) & ~(size_t)255);
+    SCK(hipMalloc((void **)&dIn, off[9] + 256));
+    for (int k = 0; k < 9; k++)
+      if (sizes[k]) SCK(hipMemcpyAsync(dIn + off[k], src[k], sizes[k], hipMemcpyHostToDevice, st));
+    SCK(hipFuncSetAttribute((const void *)ks_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ld * bd)));
+    hipLaunchKernelGGL(ks_schur_row, dim3(n), dim3(256), ld * bd, st, dS, ld, n, actx->rho, actx->sigma,
+                       (const int *)(dIn + off[0]), (const int *)(dIn + off[1]), (const double *)(dIn + off[2]),
+                       (const int *)(dIn + off[3]), (const int *)(dIn + off[4]), (const double *)(dIn + off[5]),
+                       (const int *)(dIn + off[6]), (const int *)(dIn + off[7]), (const double *)(dIn + off[8]));
+  }
   SCK(hipMemsetAsync(dX, 0, mat, st));
   SCK(hipMemsetAsync(dT, 0, mat, st));
   SCK(hipMemsetAsync(dflag, 0, sizeof(int), st));
@@ -258,6 +315,7 @@ int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double 
     dS = dT = nullptr;
   }
 done:
+  if (dIn) hipFree(dIn);
   if (dS) hipFree(dS);
   hipFree(dX);
   if (dT) hipFree(dT);

@@ -333,6 +333,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   }
   miosqp::DenseAccelCtx actx;
   actx.keep_on_device = on_dev && !(want_fold && M > 0) && !getenv("MIOSQP_SETUP_ROUNDTRIP");
+  actx.schur_on_device = on_dev && M > 0 && !getenv("MIOSQP_SETUP_HOST_SCHUR");
   if (!miosqp::build_factor(e->sc, Pp, Pi, Px, s->rho, s->sigma, e->fa, err,
                             on_dev ? miosqp_device_ldl_inverse : nullptr, &actx)) {
     g_err = err;

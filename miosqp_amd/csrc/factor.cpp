@@ -398,7 +398,26 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
   }
   tm.lap("P rows");
   // ---- Schur complement S = Pbar + sigma I + rho Abar^T Abar (dense, lower, row-major) -----
-  std::vector<double> S((size_t)n * ld, 0.0);
+  DenseAccelCtx *actx_s = static_cast<DenseAccelCtx *>(accel_ctx);
+  bool schur_dev = accel && actx_s && actx_s->schur_on_device && (size_t)n * sizeof(double) <= 150 * 1024;
+  if (schur_dev) {
+    // the device scatter of Pbar's columns needs distinct row indices within a column
+    for (int j = 0; j < n && schur_dev; j++)
+      for (int p = s.Pp[j] + 1; p < s.Pp[j + 1]; p++)
+        if (s.Pi[p] <= s.Pi[p - 1]) { schur_dev = false; break; }
+  }
+  std::vector<double> S;
+  if (schur_dev) {
+    actx_s->rho = rho; actx_s->sigma = sigma; actx_s->M = M;
+    actx_s->Pp = s.Pp.data(); actx_s->Pi = s.Pi.data(); actx_s->Px = s.Px.data(); actx_s->nnzP = (int64_t)s.Pi.size();
+    actx_s->Ap = s.Ap.data(); actx_s->Ai = s.Ai.data(); actx_s->Ax = s.Ax.data(); actx_s->nnzA = (int64_t)s.Ai.size();
+    actx_s->Rptr = f.panel_by_con.ptr.data(); actx_s->Ridx = f.panel_by_con.idx.data(); actx_s->Rval = f.A_val.data();
+    actx_s->nnzR = (int64_t)f.panel_by_con.idx.size();
+  } else if (actx_s) {
+    actx_s->schur_on_device = 0;
+  }
+  auto assemble_host = [&]() {
+  S.assign((size_t)n * ld, 0.0);
   for (int j = 0; j < n; j++)
     for (int p = s.Pp[j]; p < s.Pp[j + 1]; p++) S[(size_t)j * ld + s.Pi[p]] += s.Px[p];  // (j >= i)
   for (int j = 0; j < n; j++) S[(size_t)j * ld + j] += sigma;
@@ -415,12 +434,14 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
         for (int k = R.ptr[r]; k < R.ptr[r + 1]; k++) {
           int i2 = R.idx[k];
           if (i2 > i1) break;  // row sorted by column; padding repeats the last column
-          out[i2] += w * f.A_val[k];
+          out[i2] = std::fma(w, f.A_val[k], out[i2]);  // (explicitly fused: the device assembly does the same)
         }
       }
     });
     // padding entries carry value 0, so a repeated last column adds nothing
   }
+  };
+  if (!schur_dev) assemble_host();
   tm.lap("Schur complement");
   if (accel) {
     // dense LDL^T, triangular inverse and transpose on the device
@@ -433,8 +454,8 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
       f.Linv.assign((size_t)n * ld, 0.0);
       f.LinvT.assign((size_t)n * ld, 0.0);
     }
-    const int rc = accel(n, ld, S.data(), dd.data(), keep ? nullptr : f.Linv.data(), keep ? nullptr : f.LinvT.data(),
-                         accel_ctx);
+    const int rc = accel(n, ld, schur_dev ? nullptr : S.data(), dd.data(), keep ? nullptr : f.Linv.data(),
+                         keep ? nullptr : f.LinvT.data(), accel_ctx);
     if (rc == 1) {
       err = "KKT factorisation: non-positive pivot in the reduced Hessian (P not PSD?)";
       return false;
@@ -447,6 +468,7 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
       return true;
     }
     // device error: fall through to the host path
+    if (S.empty()) assemble_host();
   }
   // ---- blocked right-looking LDL^T of S (in place: strict lower = L22, diag = D22) ------
   std::vector<double> d(n);

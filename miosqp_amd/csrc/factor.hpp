@@ -96,6 +96,20 @@ struct DenseAccelCtx {
   void *stream = nullptr;
   int keep_on_device = 0;
   double *dLinv = nullptr, *dLinvT = nullptr;
+  // schur_on_device: the accelerator is called with S == nullptr and assembles S = Pbar + sigma I + rho Abar^T Abar
+  // itself from the arrays below (host pointers, filled in by build_factor), with the host loop's order of
+  // additions per entry (constraint rows ascending, fused multiply-add): bitwise the same S.  Saves the 200 MB host
+  // array, its assembly and its upload at n = 5000.
+  int schur_on_device = 0;
+  double rho = 0, sigma = 0;
+  const int *Pp = nullptr, *Pi = nullptr;  // scaled P, upper triangle, CSC (row indices strictly ascending per column)
+  const double *Px = nullptr;
+  const int *Ap = nullptr, *Ai = nullptr;  // scaled A, CSC
+  const double *Ax = nullptr;
+  const int *Rptr = nullptr, *Ridx = nullptr;  // rows of Abar (padded rows, see PCsr) ...
+  const double *Rval = nullptr;                // ... with the values of Abar
+  int64_t nnzP = 0, nnzA = 0, nnzR = 0;        // array lengths
+  int M = 0;
 };
 
 // Builds the factor; returns false with `err` set when D22 loses positivity.

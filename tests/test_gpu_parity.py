@@ -669,6 +669,25 @@ def test_device_setup_matches_host_setup(oracle_mod, n, m, p, seed):
             assert rel(a, b) <= ITER_TOL
     for a, b in zip(outs[0], outs[1]):
         assert rel(a, b) <= 1e-11
+    # the device stage in its three shapes -- Schur complement assembled on the device or uploaded from the host,
+    # Linv left on the device or sent down and up again -- gives bitwise the same factor: identical iterates
+    import os
+    variants = []
+    for env in ({}, {"MIOSQP_SETUP_HOST_SCHUR": "1"}, {"MIOSQP_SETUP_ROUNDTRIP": "1", "MIOSQP_SETUP_HOST_SCHUR": "1"}):
+        os.environ.update(env)
+        try:
+            g = qp.OSQP()
+            g.setup(pr["P"], pr["q"], A, l, u, setup_on_device=1, resident=0, coop=0, fold=0, **problems.QP_SETTINGS)
+            g.warm_start(x=x0, y=y0)
+            variants.append(g.debug_iterate(40))
+        finally:
+            for k in env:
+                del os.environ[k]
+    for got in variants[1:]:
+        for a, b in zip(variants[0], got):
+            np.testing.assert_array_equal(a, b)
+    for a, b in zip(variants[0], ref):
+        assert rel(a, b) <= ITER_TOL
 
 
 def _infeasible_variants(pr):
