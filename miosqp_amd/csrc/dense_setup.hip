@@ -326,6 +326,174 @@ done:
 }
 
 // ------------------------------------------------------------------------------------------
+// Equilibration on the device (miosqp::RuizOps, factor.hpp): column / row maxima and element-wise products over
+// device-resident copies of P (upper triangle, CSC) and A (CSC).  Maxima of non-negative doubles are taken on their
+// bit patterns with integer atomics (order-independent); the products are the host's two roundings
+// (t = dt[col] * dt[row], then value * t).  One wavefront per column.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct DevRuiz {
+  hipStream_t st = nullptr;
+  int n = 0, M = 0;
+  int64_t nnzP = 0, nnzA = 0;
+  char *buf = nullptr;  // one allocation: Pp Pi Px Ap Ai Ax dt et dn en
+  int *Pp = nullptr, *Pi = nullptr, *Ap = nullptr, *Ai = nullptr;
+  double *Px = nullptr, *Ax = nullptr, *dt = nullptr, *et = nullptr;
+  unsigned long long *dn = nullptr, *en = nullptr;
+};
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void kr_norms(int n, const int *__restrict__ Pp, const int *__restrict__ Pi,
+                                                const double *__restrict__ Px, const int *__restrict__ Ap,
+                                                const int *__restrict__ Ai, const double *__restrict__ Ax,
+                                                unsigned long long *dn, unsigned long long *en, int with_A) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n) return;
+  double m = 0.0;
+  for (int p = Pp[j] + lane; p < Pp[j + 1]; p += 64) {
+    const double a = fabs(Px[p]);
+    m = fmax(m, a);
+    const int i = Pi[p];
+    if (i != j) atomicMax(dn + i, (unsigned long long)__double_as_longlong(a));
+  }
+  if (with_A)
+    for (int p = Ap[j] + lane; p < Ap[j + 1]; p += 64) {
+      const double a = fabs(Ax[p]);
+      m = fmax(m, a);
+      atomicMax(en + Ai[p], (unsigned long long)__double_as_longlong(a));
+    }
+  m = wave_max_d(m);
+  if (lane == 0) atomicMax(dn + j, (unsigned long long)__double_as_longlong(m));
+}
+
+__global__ __launch_bounds__(256) void kr_scale(int n, const int *__restrict__ Pp, const int *__restrict__ Pi, double *Px,
+                                                const int *__restrict__ Ap, const int *__restrict__ Ai, double *Ax,
+                                                const double *__restrict__ dt, const double *__restrict__ et) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n) return;
+  const double dj = dt[j];
+  for (int p = Pp[j] + lane; p < Pp[j + 1]; p += 64) {
+    const double t = dj * dt[Pi[p]];
+    Px[p] = Px[p] * t;
+  }
+  for (int p = Ap[j] + lane; p < Ap[j + 1]; p += 64) {
+    const double t = dj * et[Ai[p]];
+    Ax[p] = Ax[p] * t;
+  }
+}
+
+__global__ void kr_scale_cost(int64_t nnz, double *Px, double ct) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < nnz) Px[p] = Px[p] * ct;
+}
+
+#define RCK(call)                                                                      \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      fprintf(stderr, "[miosqp setup] %s: %s\n", #call, hipGetErrorString(e__));       \
+      return -2;                                                                       \
+    }                                                                                  \
+  } while (0)
+
+int ruiz_begin(void *ctx, int n, int M, const int *Pp, const int *Pi, const double *Px, const int *Ap, const int *Ai,
+               const double *Ax) {
+  DevRuiz &r = *static_cast<DevRuiz *>(ctx);
+  r.n = n; r.M = M; r.nnzP = Pp[n]; r.nnzA = Ap[n];
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t sz[10] = {al((size_t)(n + 1) * 4), al((size_t)r.nnzP * 4), al((size_t)r.nnzP * 8), al((size_t)(n + 1) * 4),
+                         al((size_t)r.nnzA * 4), al((size_t)r.nnzA * 8), al((size_t)n * 8), al((size_t)(M + 1) * 8),
+                         al((size_t)n * 8), al((size_t)(M + 1) * 8)};
+  size_t off[11];
+  off[0] = 0;
+  for (int k = 0; k < 10; k++) off[k + 1] = off[k] + sz[k];
+  RCK(hipMalloc((void **)&r.buf, off[10] + 256));
+  r.Pp = (int *)(r.buf + off[0]); r.Pi = (int *)(r.buf + off[1]); r.Px = (double *)(r.buf + off[2]);
+  r.Ap = (int *)(r.buf + off[3]); r.Ai = (int *)(r.buf + off[4]); r.Ax = (double *)(r.buf + off[5]);
+  r.dt = (double *)(r.buf + off[6]); r.et = (double *)(r.buf + off[7]);
+  r.dn = (unsigned long long *)(r.buf + off[8]); r.en = (unsigned long long *)(r.buf + off[9]);
+  RCK(hipMemcpyAsync(r.Pp, Pp, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, r.st));
+  RCK(hipMemcpyAsync(r.Pi, Pi, (size_t)r.nnzP * 4, hipMemcpyHostToDevice, r.st));
+  RCK(hipMemcpyAsync(r.Px, Px, (size_t)r.nnzP * 8, hipMemcpyHostToDevice, r.st));
+  RCK(hipMemcpyAsync(r.Ap, Ap, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, r.st));
+  if (r.nnzA) {
+    RCK(hipMemcpyAsync(r.Ai, Ai, (size_t)r.nnzA * 4, hipMemcpyHostToDevice, r.st));
+    RCK(hipMemcpyAsync(r.Ax, Ax, (size_t)r.nnzA * 8, hipMemcpyHostToDevice, r.st));
+  }
+  return 0;
+}
+
+int ruiz_norms(void *ctx, double *dt, double *et, int with_A) {
+  DevRuiz &r = *static_cast<DevRuiz *>(ctx);
+  RCK(hipMemsetAsync(r.dn, 0, (size_t)r.n * 8, r.st));
+  if (with_A) RCK(hipMemsetAsync(r.en, 0, (size_t)(r.M + 1) * 8, r.st));
+  hipLaunchKernelGGL(kr_norms, dim3((r.n + 3) / 4), dim3(256), 0, r.st, r.n, r.Pp, r.Pi, r.Px, r.Ap, r.Ai, r.Ax, r.dn, r.en,
+                     with_A);
+  RCK(hipMemcpyAsync(dt, r.dn, (size_t)r.n * 8, hipMemcpyDeviceToHost, r.st));
+  if (with_A && r.M) RCK(hipMemcpyAsync(et, r.en, (size_t)r.M * 8, hipMemcpyDeviceToHost, r.st));
+  RCK(hipStreamSynchronize(r.st));
+  return 0;
+}
+
+int ruiz_scale(void *ctx, const double *dt, const double *et) {
+  DevRuiz &r = *static_cast<DevRuiz *>(ctx);
+  RCK(hipMemcpyAsync(r.dt, dt, (size_t)r.n * 8, hipMemcpyHostToDevice, r.st));
+  if (r.M) RCK(hipMemcpyAsync(r.et, et, (size_t)r.M * 8, hipMemcpyHostToDevice, r.st));
+  RCK(hipStreamSynchronize(r.st));  // the sources are the caller's vectors
+  hipLaunchKernelGGL(kr_scale, dim3((r.n + 3) / 4), dim3(256), 0, r.st, r.n, r.Pp, r.Pi, r.Px, r.Ap, r.Ai, r.Ax, r.dt, r.et);
+  return 0;
+}
+
+int ruiz_scale_cost(void *ctx, double ct) {
+  DevRuiz &r = *static_cast<DevRuiz *>(ctx);
+  if (r.nnzP)
+    hipLaunchKernelGGL(kr_scale_cost, dim3((unsigned)((r.nnzP + 255) / 256)), dim3(256), 0, r.st, r.nnzP, r.Px, ct);
+  return 0;
+}
+
+int ruiz_end(void *ctx, double *Px, double *Ax) {
+  DevRuiz &r = *static_cast<DevRuiz *>(ctx);
+  int rc = 0;
+  if (r.buf) {
+    if (hipMemcpyAsync(Px, r.Px, (size_t)r.nnzP * 8, hipMemcpyDeviceToHost, r.st) != hipSuccess) rc = -2;
+    if (r.nnzA && hipMemcpyAsync(Ax, r.Ax, (size_t)r.nnzA * 8, hipMemcpyDeviceToHost, r.st) != hipSuccess) rc = -2;
+    if (hipStreamSynchronize(r.st) != hipSuccess) rc = -2;
+    hipFree(r.buf);
+    r.buf = nullptr;
+  }
+  return rc;
+}
+
+}  // namespace
+
+// fills `ops` with the device implementation; `storage` must stay alive until ops->end has been called
+struct MiosqpDevRuizStorage {
+  DevRuiz r;
+};
+void miosqp_device_ruiz_ops(miosqp::RuizOps *ops, void **storage, void *stream) {
+  MiosqpDevRuizStorage *s = new MiosqpDevRuizStorage();
+  s->r.st = (hipStream_t)stream;
+  *storage = s;
+  ops->ctx = &s->r;
+  ops->begin = ruiz_begin;
+  ops->norms = ruiz_norms;
+  ops->scale = ruiz_scale;
+  ops->scale_cost = ruiz_scale_cost;
+  ops->end = ruiz_end;
+}
+void miosqp_device_ruiz_free(void *storage) {
+  MiosqpDevRuizStorage *s = static_cast<MiosqpDevRuizStorage *>(storage);
+  if (s && s->r.buf) hipFree(s->r.buf);
+  delete s;
+}
+
+// ------------------------------------------------------------------------------------------
 // Explicit KKT inverse for the register-resident cooperative solver (engine.hip, k_coop):
 //   W = F^T D22^-1 F ,   F = [ -G | L22^-1 ]  (n x N, N = M + n; the rows of the product-form
 //   factor with their unit diagonal restored),  so that  W [wh ; rx] = [ rho A x~ + .. ; x~ ].

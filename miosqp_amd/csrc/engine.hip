@@ -41,6 +41,8 @@
 
 // dense_setup.hip: dense LDL^T + triangular inverse on the device (miosqp::DenseLdlInv)
 int miosqp_device_ldl_inverse(int n, int ld, const double *S, double *d, double *Linv, double *LinvT, void *ctx);
+void miosqp_device_ruiz_ops(miosqp::RuizOps *ops, void **storage, void *stream);
+void miosqp_device_ruiz_free(void *storage);
 // dense_setup.hip: explicit KKT inverse W = F^T D22^-1 F from the product-form rows (device pointers)
 int miosqp_device_kkt_inverse(const double *F, int ldf, const double *dinv, int n, int M, double *W, int ldw,
                               hipStream_t stream);
@@ -307,12 +309,24 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->st = *s;
   if (e->st.check_termination <= 0 || e->st.check_termination > e->st.max_iter)
     e->st.check_termination = e->st.max_iter;
-  miosqp::scale_problem(n, M, Pp, Pi, Px, Ap, Ai, Ax, q, s->scaling, e->sc);
   std::string err;
-  // dense part of the factorisation on the device for large problems
+  // the array-sized parts of the setup on the device for large problems: the equilibration's
+  // maxima and products, the Schur complement, the dense LDL^T and its triangular inverse
   int on_dev = s->setup_on_device;
   if (on_dev < 0) on_dev = n >= 1024 ? 1 : 0;
   e->setup_on_device = on_dev != 0;
+  {
+    bool done = false;
+    if (on_dev && s->scaling > 0 && !getenv("MIOSQP_SETUP_HOST_RUIZ")) {
+      miosqp::RuizOps ops;
+      void *storage = nullptr;
+      miosqp_device_ruiz_ops(&ops, &storage, nullptr);
+      done = miosqp::scale_problem(n, M, Pp, Pi, Px, Ap, Ai, Ax, q, s->scaling, e->sc, &ops);
+      miosqp_device_ruiz_free(storage);
+      if (!done) fprintf(stderr, "miosqp: equilibration on the device failed, redone on the host\n");
+    }
+    if (!done) miosqp::scale_problem(n, M, Pp, Pi, Px, Ap, Ai, Ax, q, s->scaling, e->sc);
+  }
   // Will the product form be built (on the host, from Linv)?  Decided here because the device stage of the setup may
   // then leave Linv / LinvT on the device instead of sending them down and up again.
   int want_fold = s->fold;

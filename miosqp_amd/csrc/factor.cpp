@@ -223,9 +223,9 @@ void pack_rows(int rows, int cols, std::vector<std::vector<Triplet>> &r, PCsr &o
 
 }  // namespace
 
-void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
+bool scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
                    const int32_t *Ap, const int32_t *Ai, const double *Ax, const double *q,
-                   int passes, Scaled &s) {
+                   int passes, Scaled &s, const RuizOps *ops) {
   StageTimer tm;
   s.n = n;
   s.M = M;
@@ -249,7 +249,13 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
   s.E.assign(M, 1.0);
   s.c = 1.0;
   std::vector<double> dt(n), et(M);
-  for (int pass = 0; pass < passes; pass++) {
+  const bool dev = ops && passes > 0;
+  bool dev_ok = true;
+  if (dev) dev_ok = ops->begin(ops->ctx, n, M, s.Pp.data(), s.Pi.data(), s.Px.data(), s.Ap.data(), s.Ai.data(), s.Ax.data()) == 0;
+  for (int pass = 0; pass < passes && dev_ok; pass++) {
+    if (dev) {
+      if (ops->norms(ops->ctx, dt.data(), et.data(), 1)) { dev_ok = false; break; }
+    } else {
     sym_col_norms(n, s.Pp, s.Pi, s.Px, dt);
     std::fill(et.begin(), et.end(), 0.0);
     for (int j = 0; j < n; j++)
@@ -258,8 +264,12 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
         dt[j] = std::max(dt[j], a);
         et[s.Ai[p]] = std::max(et[s.Ai[p]], a);
       }
+    }
     for (int j = 0; j < n; j++) dt[j] = 1.0 / std::sqrt(clamp_scaling(dt[j]));
     for (int i = 0; i < M; i++) et[i] = 1.0 / std::sqrt(clamp_scaling(et[i]));
+    if (dev) {
+      if (ops->scale(ops->ctx, dt.data(), et.data())) { dev_ok = false; break; }
+    } else {
     parallel_chunks(kColChunks, (int64_t)s.Pp[n] / kColChunks + 1, [&](int64_t c) {
       int lo, hi;
       col_range(n, c, lo, hi);
@@ -268,33 +278,47 @@ void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
     });
     for (int j = 0; j < n; j++)
       for (int p = s.Ap[j]; p < s.Ap[j + 1]; p++) s.Ax[p] *= dt[j] * et[s.Ai[p]];
+    }
     for (int j = 0; j < n; j++) {
       s.q[j] *= dt[j];
       s.D[j] *= dt[j];
     }
     for (int i = 0; i < M; i++) s.E[i] *= et[i];
     // cost normalisation
-    sym_col_norms(n, s.Pp, s.Pi, s.Px, dt);
+    if (dev) {
+      if (ops->norms(ops->ctx, dt.data(), nullptr, 0)) { dev_ok = false; break; }
+    } else {
+      sym_col_norms(n, s.Pp, s.Pi, s.Px, dt);
+    }
     double mean = 0;
     for (int j = 0; j < n; j++) mean += dt[j];
     mean /= n;
     double nq = 0;
     for (int j = 0; j < n; j++) nq = std::max(nq, std::fabs(s.q[j]));
     double ct = 1.0 / clamp_scaling(std::max(mean, clamp_scaling(nq)));
+    if (dev) {
+      if (ops->scale_cost(ops->ctx, ct)) { dev_ok = false; break; }
+    } else {
     parallel_chunks(kColChunks, (int64_t)s.Pp[n] / kColChunks + 1, [&](int64_t c) {
       int lo, hi;
       col_range(n, c, lo, hi);
       for (int p = s.Pp[lo]; p < s.Pp[hi]; p++) s.Px[p] *= ct;
     });
+    }
     for (double &v : s.q) v *= ct;
     s.c *= ct;
   }
-  tm.lap("copy + Ruiz equilibration");
+  if (dev) {
+    if (ops->end(ops->ctx, s.Px.data(), s.Ax.data())) dev_ok = false;
+    if (!dev_ok) return false;  // the caller repeats the call on the host
+  }
+  tm.lap(dev ? "copy + Ruiz equilibration (device)" : "copy + Ruiz equilibration");
   s.Dinv.resize(n);
   s.Einv.resize(M);
   for (int j = 0; j < n; j++) s.Dinv[j] = 1.0 / s.D[j];
   for (int i = 0; i < M; i++) s.Einv[i] = 1.0 / s.E[i];
   s.cinv = 1.0 / s.c;
+  return true;
 }
 
 bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,

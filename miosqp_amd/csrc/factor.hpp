@@ -77,10 +77,30 @@ struct Folded {
 };
 void build_folded(const Factor &f, Folded &out);
 
-// Ruiz equilibration + cost normalisation (OSQP paper sec. 5.1).  P: CSC, only row<=col read.
-void scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
+// Optional accelerator for the equilibration: the three array-sized operations of a pass
+// on device-resident copies of the matrices.  They are maxima and element-wise products only, so the result is
+// bitwise the host's; everything scalar (square roots, clamps, the mean of the norms -- a serial sum --, q, D, E, c)
+// stays in scale_problem.  Every function returns 0 on success.
+struct RuizOps {
+  void *ctx = nullptr;
+  // upload (upper triangle of P and A, CSC)
+  int (*begin)(void *ctx, int n, int M, const int *Pp, const int *Pi, const double *Px, const int *Ap, const int *Ai,
+               const double *Ax) = nullptr;
+  // dt[j] = max(|P(:, j)| as a symmetric matrix, with_A ? |A(:, j)| : 0); et[i] = |A(i, :)| (with_A only)
+  int (*norms)(void *ctx, double *dt, double *et, int with_A) = nullptr;
+  // Px[p] *= dt[col] * dt[row];  Ax[p] *= dt[col] * et[row]
+  int (*scale)(void *ctx, const double *dt, const double *et) = nullptr;
+  // Px[p] *= ct
+  int (*scale_cost)(void *ctx, double ct) = nullptr;
+  // download the scaled values; releases the device copies (also to be called after an error)
+  int (*end)(void *ctx, double *Px, double *Ax) = nullptr;
+};
+
+// Ruiz equilibration + cost normalisation (OSQP paper sec. 5.1).  P: CSC, only row<=col read.  Returns false when
+// `ops` failed (the caller repeats the call without it); always true without `ops`.
+bool scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const double *Px,
                    const int32_t *Ap, const int32_t *Ai, const double *Ax, const double *q,
-                   int passes, Scaled &out);
+                   int passes, Scaled &out, const RuizOps *ops = nullptr);
 
 // Optional accelerator for the dense part of the setup: given the
 // reduced Hessian S (n x ld row-major, lower triangle valid) it must produce d (D22), Linv

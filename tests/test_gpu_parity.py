@@ -669,11 +669,13 @@ def test_device_setup_matches_host_setup(oracle_mod, n, m, p, seed):
             assert rel(a, b) <= ITER_TOL
     for a, b in zip(outs[0], outs[1]):
         assert rel(a, b) <= 1e-11
-    # the device stage in its three shapes -- Schur complement assembled on the device or uploaded from the host,
-    # Linv left on the device or sent down and up again -- gives bitwise the same factor: identical iterates
+    # the device stages in their shapes -- equilibration's maxima / products on the device or on the host, Schur
+    # complement assembled on the device or uploaded from the host, Linv left on the device or sent down and up again
+    # -- give bitwise the same scaling and factor: identical iterates
     import os
     variants = []
-    for env in ({}, {"MIOSQP_SETUP_HOST_SCHUR": "1"}, {"MIOSQP_SETUP_ROUNDTRIP": "1", "MIOSQP_SETUP_HOST_SCHUR": "1"}):
+    for env in ({}, {"MIOSQP_SETUP_HOST_SCHUR": "1"}, {"MIOSQP_SETUP_HOST_RUIZ": "1"},
+                {"MIOSQP_SETUP_ROUNDTRIP": "1", "MIOSQP_SETUP_HOST_SCHUR": "1", "MIOSQP_SETUP_HOST_RUIZ": "1"}):
         os.environ.update(env)
         try:
             g = qp.OSQP()
