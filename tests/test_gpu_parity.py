@@ -1195,6 +1195,32 @@ def test_hosted_search_equals_the_python_loop(n, m, p, seed, rule):
         assert r3.upper_glob == r0.upper_glob - 1e-6 and cc.work.iter_num <= py.work.iter_num
 
 
+@pytest.mark.parametrize("form", [dict(coop=0, resident=0), dict(fold=0, coop=0, resident=0), dict(resident=1)])
+def test_hosted_search_on_every_engine_form(form):
+    """The hosted loop drives whatever form the engine uses for single nodes (two-kernel product form with host-checked
+    chunks, four-kernel factor form, LDS-resident workgroup): same nodes and iterations as the Python loop on that form;
+    a store with too few slots reports MIOSQP_EFULL instead of overwriting leaves."""
+    from miosqp_amd import bnb, search
+    pr = problems.random_miqp(40, 60, 20, seed=7)
+    st = dict(problems.BNB_SETTINGS, device_tree=False)
+    qs = dict(problems.QP_SETTINGS, **form)
+    py, cc = bnb.MIOSQP(), bnb.MIOSQP()
+    py.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st, device_search=False), dict(qs))
+    cc.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st), dict(qs))
+    r0, r1 = py.solve(), cc.solve()
+    assert getattr(cc.work, "_hosted", None) is not None
+    assert (r1.status, cc.work.iter_num, cc.work.osqp_iter) == (r0.status, py.work.iter_num, py.work.osqp_iter)
+    assert abs(r1.upper_glob - r0.upper_glob) <= 1e-9 * max(1.0, abs(r0.upper_glob))
+    np.testing.assert_array_equal(r1.x[pr["i_idx"]], r0.x[pr["i_idx"]])
+    # four slots: the root and its two children fit, the grandchildren do not
+    tiny = bnb.MIOSQP()
+    tiny.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st, device_search=False), dict(qs))
+    hs = search.HostedSearch(tiny, capacity=4)
+    if py.work.iter_num > 4:
+        with pytest.raises(RuntimeError, match="no free slot"):
+            hs.run()
+
+
 def test_hosted_search_at_config2_size():
     """Config 2 (n=500, m=1000, p=250) through the hosted search in the engine's cooperative form: the first 40 nodes
     equal the Python loop's (nodes, iterations, incumbent)."""
