@@ -10,8 +10,11 @@ the reference's settings (run_example.py:98-116).  One "step" = one wave = `--wa
 relaxations per rank (default 1: node-at-a-time) followed by the incumbent exchange.  When a tree
 closes (seed 0 closes after ~220 nodes) the search re-roots on the next MIQP of a stream that shares
 P and A -- hence the factor -- and draws new q, l, u, through MIOSQP.update_vectors.  Inputs
-(factor, matrices) are resident in HBM before the timed region; the per-node vectors (l, u, x0,
-y0: 34 KB) are part of the path and travel inside it.  N > 1 shards the open leaves over the
+(factor, matrices) are resident in HBM before the timed region.  The loop between two nodes
+(choose_leaf, bound_and_branch, prune: /root/reference/miosqp/solver.py:85-123) runs in the C++ host
+library on device-resident leaves (miosqp_amd/search.py; a 96-byte record per node crosses PCIe);
+--python-loop drives every node from bnb.Workspace in Python instead (per-node vectors l, u, x0, y0:
+34 KB each way), and the `python_loop` leg reports that form next to `value`.  N > 1 shards the open leaves over the
 ranks (miosqp_amd/dist.py), one process per GPU, RCCL only for the incumbent: weak scaling.
 
 Extra legs in the same JSON line (none of them is part of `value`):
@@ -21,6 +24,8 @@ Extra legs in the same JSON line (none of them is part of `value`):
   config5   BASELINE configs[4]: n=5000, the bandwidth-bound single-node case
   config4   BASELINE configs[3]: the power-converter MPC sequence (40 MIQPs, n=18)
   cpu_baseline  the reference's CPU path (real OSQP when importable, else the oracle) on this box's host cores
+  python_loop   the headline workload with the reference's control flow unchanged (bnb.Workspace in Python driving
+            miosqp_qp_solve_node); `value` itself runs the same loop compiled into the host library
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 KERNELS = ["k_panel_fwd", "k_tail_fwd", "k_tail_bwd", "k_panel_bwd"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-ALL_LEGS = ("batched", "stream", "config5", "config4", "cpu")
+ALL_LEGS = ("batched", "stream", "config5", "config4", "cpu", "pyloop")
 
 
 def pmc_traffic(kernel, tag=""):
@@ -441,6 +446,24 @@ def main():
                      mean_nodes_per_tree=round(float(np.mean([c[1] for c in closed[1:]])), 1),
                      trees_per_s=round(1.0 / float(np.mean(gaps)), 2))
 
+    # ---- extra leg: the same node-at-a-time workload with the reference's own control flow -- bnb.Workspace in
+    #      Python driving miosqp_qp_solve_node, vectors over PCIe per node -- next to the hosted loop of `value`
+    pyloop = None
+    if hosted and "pyloop" in legs and world == 1:
+        next_instance()
+        run_steps(10, args.wave, False)
+        sync()
+        np0, ip0 = srch.nodes, srch.iters
+        tp = time.perf_counter()
+        run_steps(min(args.steps, 100), args.wave, False)
+        srch.drain()
+        sync()
+        dtp = time.perf_counter() - tp
+        pyloop = dict(what="bnb.Workspace (Python) driving miosqp_qp_solve_node: the reference's control flow unchanged",
+                      value=round((srch.iters - ip0) / dtp, 1), unit="ADMM iter/s", nodes=srch.nodes - np0,
+                      nodes_per_s=round((srch.nodes - np0) / dtp, 2),
+                      iters_per_node=round((srch.iters - ip0) / max(1.0, float(srch.nodes - np0)), 1))
+
     # ---- extra leg (BASELINE configs[2]): the same MIQP stream with `batch_width` leaves in flight per rank
     #      (not part of `value`).  Two forms: WAVES (each wave one batched device call: a wave waits for its
     #      slowest leaf, vectors cross PCIe) and the STREAM on the device-resident leaf pool (columns refilled
@@ -627,6 +650,8 @@ def main():
                                comm=type(comm).__name__ + ("/nccl" if (td is not None and not one_dev) else "")),
                    roofline=roof)
         out["config"]["instances_in_timed_region"] = instances
+        if pyloop is not None:
+            out["python_loop"] = pyloop
         if batched is not None and batched["lockstep_iters"] > 0:
             bk = []
             if not args.no_probes:
