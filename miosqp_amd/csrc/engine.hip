@@ -733,9 +733,10 @@ int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *
   }
   ENTER(e);
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (e->M > 0) {
-    HIPCHK(hipMemcpy(e->d.root_l, l_root, sizeof(double) * e->M, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d.root_u, u_root, sizeof(double) * e->M, hipMemcpyHostToDevice));
+  if (e->M > 0) {  // (on the engine's stream: see miosqp_qp_pool_write_node)
+    HIPCHK(hipMemcpyAsync(e->d.root_l, l_root, sizeof(double) * e->M, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d.root_u, u_root, sizeof(double) * e->M, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
   }
   if (e->x_stream && (e->d.eps_int != eps_int_feas || e->d.eps_lin != eps_lin)) drop_stream_graph(e);  // captured by value
   e->d.eps_int = eps_int_feas;

@@ -14,11 +14,122 @@ iterations, so a node never waits for the slowest node of a wave.  Nodes are pus
 exploration rule would pick them at push time; as in wave mode the visiting order differs from the
 reference's one-node-at-a-time order, per-node results do not (tests/test_gpu_parity.py).
 """
+import collections
+import heapq
+
 import numpy as np
 
 from miosqp_amd import bnb
 
 PRUNED = -100
+
+
+class OpenLeaves(object):
+    """The open leaves that have not been pushed to the device yet, kept so that "the next `k` leaves in the exploration
+    rule's order" costs O(k) instead of a sort of all of them at every chunk (thousands at config 2: the sort was the
+    largest item of the host's time per chunk).  Same order as a stable sort of the creation-ordered list by the key:
+    depth first = the deepest leaves, older first (buckets by depth, each in creation order); best first in the
+    reference's sense (workspace.py:142-149: the LARGEST inherited bound) = a heap on (-lower, creation number).
+    len(), iteration (creation order) and append() as a list."""
+
+    def __init__(self, depth, lower):
+        self._depth, self._lower = depth, lower  # per-slot lists owned by the search
+        self.clear()
+
+    def clear(self):
+        self._seq = {}       # slot -> creation number, for the leaves present
+        self._count = 0
+        self._buckets = {}   # depth -> deque of slots (creation order); depth mode
+        self._maxd = -1
+        self._heap = None    # [(-lower, creation number, slot)]; lower mode (entries of absent slots are skipped)
+
+    def __len__(self):
+        return len(self._seq)
+
+    def __iter__(self):
+        return iter(sorted(self._seq, key=self._seq.get))
+
+    def __bool__(self):
+        return bool(self._seq)
+
+    def append(self, s):
+        self._seq[s] = self._count
+        if self._heap is not None:
+            heapq.heappush(self._heap, (-self._lower[s], self._count, s))
+        else:
+            d = self._depth[s]
+            b = self._buckets.get(d)
+            if b is None:
+                b = self._buckets[d] = collections.deque()
+            b.append(s)
+            if d > self._maxd:
+                self._maxd = d
+        self._count += 1
+
+    def _to_heap(self):
+        self._heap = [(-self._lower[s], q, s) for s, q in self._seq.items()]
+        heapq.heapify(self._heap)
+        self._buckets = {}
+
+    def take(self, k, by_lower):
+        """Removes and returns the next (at most) k leaves: by_lower False -> deepest first, True -> largest bound first."""
+        out = []
+        if k <= 0 or not self._seq:
+            return out
+        if by_lower:
+            if self._heap is None:
+                self._to_heap()
+            h = self._heap
+            while h and len(out) < k:
+                _, q, s = heapq.heappop(h)
+                if self._seq.get(s) == q:
+                    del self._seq[s]
+                    out.append(s)
+            return out
+        if self._heap is not None:  # (a search that went back to depth first: rebuild the buckets)
+            self._heap = None
+            self._buckets, self._maxd = {}, -1
+            for s in sorted(self._seq, key=self._seq.get):
+                self._buckets.setdefault(self._depth[s], collections.deque()).append(s)
+                self._maxd = max(self._maxd, self._depth[s])
+        d = self._maxd
+        while d >= 0 and len(out) < k:
+            b = self._buckets.get(d)
+            if b:
+                while b and len(out) < k:
+                    s = b.popleft()
+                    del self._seq[s]
+                    out.append(s)
+            if not b:
+                self._buckets.pop(d, None)
+                if d == self._maxd:
+                    self._maxd = d - 1
+            d -= 1
+        return out
+
+    def prune(self, upper):
+        """Removes and returns the leaves whose inherited bound exceeds `upper`."""
+        if self._heap is not None:
+            out, h = [], self._heap
+            while h and -h[0][0] > upper:
+                _, q, s = heapq.heappop(h)
+                if self._seq.get(s) == q:
+                    del self._seq[s]
+                    out.append(s)
+            return out
+        out = [s for s in self._seq if self._lower[s] > upper]
+        for s in out:
+            del self._seq[s]
+            self._buckets[self._depth[s]].remove(s)
+        return out
+
+    def pop_shallowest(self):
+        """The shallowest leaf, the oldest of them (what is handed to another rank)."""
+        s = min(self._seq, key=lambda t: (self._depth[t], self._seq[t]))
+        del self._seq[s]
+        if self._heap is None:
+            self._buckets[self._depth[s]].remove(s)
+        return s
 
 
 class StreamSearch(object):
@@ -49,18 +160,20 @@ class StreamSearch(object):
             self.eng._pool_capacity = self.capacity
         self.capacity = self.eng._pool_capacity
         cap = self.capacity
-        self.depth = np.zeros(cap, dtype=np.int64)
-        self.lower = np.full(cap, -np.inf)       # bound a node inherited; its own once solved
-        self.parent = np.full(cap, -1, dtype=np.int64)
-        self.kids_alive = np.zeros(cap, dtype=np.int64)
-        self.child = np.full((cap, 2), -1, dtype=np.int64)
+        # per-slot bookkeeping as plain lists (scalar access from the per-node logic: several times faster than numpy)
+        self.depth = [0] * cap
+        self.lower = [-np.inf] * cap             # bound a node inherited; its own once solved
+        self.parent = [-1] * cap
+        self.kids_alive = [0] * cap
+        self.child = [(-1, -1)] * cap
         self.nodes = 0
         self.iters = 0
         self.dropped = 0
         self.chunks = 0
         self.const_solved = w.constant('OSQP_SOLVED')
         self.const_maxit = w.constant('OSQP_MAX_ITER_REACHED')
-        self._decided = np.zeros(cap, dtype=bool)
+        self._decided = [False] * cap
+        self.open = OpenLeaves(self.depth, self.lower)
         self.begin_instance()
 
     # -- instance -------------------------------------------------------------------------------
@@ -69,10 +182,11 @@ class StreamSearch(object):
         no leaf at all (the sharded search hands this rank its share through add_leaf)."""
         w = self.work
         self.eng.pool_reset()
-        self._decided[:] = False
-        self.kids_alive[:] = 0
+        for k in range(self.capacity):
+            self._decided[k] = False
+            self.kids_alive[k] = 0
         self.free = list(range(self.capacity - 1, -1, -1))  # pop() hands out slot 0 first
-        self.open = []        # slots of open leaves not yet pushed, in creation order
+        self.open.clear()     # slots of open leaves not yet pushed (OpenLeaves: creation order, rule-ordered take)
         self.in_flight = 0    # pushed and not yet decided
         if seed_root:
             root = w.leaves[0] if w.leaves else w._make_root()
@@ -104,10 +218,9 @@ class StreamSearch(object):
     def give_leaf(self):
         """Takes the shallowest open leaf out of this rank's tree (the largest subtree: keeps the receiver busy
         longest) and returns it with explicit vectors: (l_int, u_int, x0, y0, depth, lower)."""
-        k = int(np.argmin(self.depth[np.asarray(self.open)]))
-        s = self.open.pop(k)
+        s = self.open.pop_shallowest()
         nd = self.eng.pool_read_node(s, self.p, want=("l", "u"))
-        ws = int(self.parent[s]) if self.parent[s] >= 0 else s  # its warm start: the parent's solution
+        ws = self.parent[s] if self.parent[s] >= 0 else s  # its warm start: the parent's solution
         sol = self.eng.pool_read_node(ws, self.p, want=("x", "y"))
         rec = (nd.l, nd.u, sol.x, sol.y, int(self.depth[s]), float(self.lower[s]))
         self._done(s)
@@ -126,75 +239,76 @@ class StreamSearch(object):
     def _done(self, s):
         """Node `s` has been decided (or discarded).  Its slot stays allocated while a child may still read its
         solution as a warm start; the last child to be decided frees it.  `s` itself no longer needs its parent."""
-        s = int(s)
         self._decided[s] = True
         if self.kids_alive[s] == 0:
             self.free.append(s)
-        par = int(self.parent[s])
+        par = self.parent[s]
         if par >= 0:
             self.kids_alive[par] -= 1
             if self.kids_alive[par] == 0 and self._decided[par]:
                 self.free.append(par)
 
     # -- host side of bound_and_branch (workspace.py:282-334) on a digest --------------------------
-    def _absorb(self, g):
+    # digest fields (include/miosqp_amd.h: miosqp_pool_digest), as positions of the row tuples
+    G_SLOT, G_STATUS, G_ITER, G_INTINF, G_NEXTVAR, G_RES, G_LOWER, G_HVIOL, G_HOBJ = range(9)
+
+    def _absorb(self, g, rec=None):
+        """g: one digest as a tuple (fields above); rec: the same as a numpy record, for the observer."""
         w = self.work
-        s = int(g["slot"])
+        s = g[0]
         if self.observer is not None:
-            self.observer(self, g)
+            self.observer(self, rec)
         self.in_flight -= 1
-        c0, c1 = int(self.child[s, 0]), int(self.child[s, 1])
-        st = int(g["status_val"])
-
-        def no_children():
-            for c in (c0, c1):
-                if c >= 0:
-                    self.free.append(c)
-            self.child[s] = -1
-            self.kids_alive[s] = 0
-
-        if st == PRUNED:
-            self.dropped += 1
-            no_children()
-            self._done(s)
-            return
-        self.nodes += 1
-        self.iters += int(g["iter"])
-        w.iter_num += 1
-        w.osqp_iter += int(g["iter"])
-        if st not in (self.const_solved, self.const_maxit):
-            no_children()
-            self._done(s)
-            return
-        lower = float(g["lower"])
-        self.lower[s] = lower
-        if lower > w.upper_glob:
-            no_children()
-            self._done(s)
-            return
-        if int(g["int_inf"]) == 0:
-            w.x = self.eng.pool_read_node(s, self.p, want=("x",)).x
-            w.upper_glob = lower
-            self.eng.pool_set_upper(w.upper_glob)
-            self._prune_open()
-            no_children()
-            self._done(s)
-            return
-        if g["heur_viol"] <= 0.0 and g["heur_obj"] < w.upper_glob:
-            x = self.eng.pool_read_node(s, self.p, want=("x",)).x
-            x_int = w.get_integer_solution(x)
-            obj_int = w.data.compute_obj_val(x_int)  # the host's own value enters upper_glob (bnb.py digest branch)
-            if obj_int < w.upper_glob:
-                w.upper_glob = obj_int
-                w.x = x_int
+        c0, c1 = self.child[s]
+        st = g[1]
+        if st == PRUNED or st not in (self.const_solved, self.const_maxit):
+            branch = False
+            if st == PRUNED:
+                self.dropped += 1
+            else:
+                self.nodes += 1
+                self.iters += g[2]
+                w.iter_num += 1
+                w.osqp_iter += g[2]
+        else:
+            self.nodes += 1
+            self.iters += g[2]
+            w.iter_num += 1
+            w.osqp_iter += g[2]
+            lower = g[6]
+            self.lower[s] = lower
+            branch = not lower > w.upper_glob
+            if branch and g[3] == 0:
+                w.x = self.eng.pool_read_node(s, self.p, want=("x",)).x
+                w.upper_glob = lower
                 self.eng.pool_set_upper(w.upper_glob)
                 self._prune_open()
+                branch = False
+            elif branch and g[7] <= 0.0 and g[8] < w.upper_glob:
+                x = self.eng.pool_read_node(s, self.p, want=("x",)).x
+                x_int = w.get_integer_solution(x)
+                obj_int = w.data.compute_obj_val(x_int)  # the host's own value enters upper_glob (bnb.py digest branch)
+                if obj_int < w.upper_glob:
+                    w.upper_glob = obj_int
+                    w.x = x_int
+                    self.eng.pool_set_upper(w.upper_glob)
+                    self._prune_open()
+        if not branch:
+            if c0 >= 0:
+                self.free.append(c0)
+            if c1 >= 0:
+                self.free.append(c1)
+            self.child[s] = (-1, -1)
+            self.kids_alive[s] = 0
+            self._done(s)
+            return
         # both children exist on the device (written by the harvest): they become open leaves
         alive = 0
+        d1 = self.depth[s] + 1
         for c in (c0, c1):
             if c < 0:
                 continue
-            self.depth[c] = self.depth[s] + 1
+            self.depth[c] = d1
             self.lower[c] = lower
             self.parent[c] = s
             self.kids_alive[c] = 0
@@ -207,14 +321,8 @@ class StreamSearch(object):
     def _prune_open(self):
         """Open leaves whose inherited bound exceeds the new incumbent are discarded (workspace.py:274-280;
         the reference's skip-one traversal quirk is not reproduced: every such leaf goes)."""
-        w = self.work
-        keep = []
-        for s in self.open:
-            if self.lower[s] > w.upper_glob:
-                self._done(s)
-            else:
-                keep.append(s)
-        self.open = keep
+        for s in self.open.prune(self.work.upper_glob):
+            self._done(s)
 
     def _push(self, ready_left):
         """Keeps the ready ring topped up with the leaves the exploration rule would take next."""
@@ -223,28 +331,21 @@ class StreamSearch(object):
         if room <= 0 or not self.open:
             return
         rule = w.settings['tree_explor_rule']
-        op = np.asarray(self.open)
-        if rule == 0 or (rule == 1 and np.isinf(w.upper_glob)):
-            keys = self.depth[op].astype(float)
-        elif rule == 1:
-            keys = self.lower[op]
-        else:
+        if rule not in (0, 1):
             raise ValueError('Tree exploring strategy not recognized')
-        order = np.argsort(-keys, kind='stable')
-        take = [int(i) for i in order[:min(room, len(self.free) // 2)]]  # two child slots each
-        if not take:
+        by_lower = rule == 1 and not np.isinf(w.upper_glob)
+        slots = self.open.take(min(room, len(self.free) // 2), by_lower)  # two child slots each
+        if not slots:
             return
-        slots = op[take]
-        c0 = np.empty(len(take), dtype=np.int32)
-        c1 = np.empty(len(take), dtype=np.int32)
-        for k, s in enumerate(slots):
-            c0[k] = self.free.pop()
-            c1[k] = self.free.pop()
-            self.child[s, 0], self.child[s, 1] = c0[k], c1[k]
-        self.eng.pool_push(slots, c0, c1, self.lower[slots])
-        self.in_flight += len(take)
-        taken = set(take)
-        self.open = [s for i, s in enumerate(self.open) if i not in taken]
+        free, child = self.free, self.child
+        c0, c1 = [], []
+        for s in slots:
+            a, b = free.pop(), free.pop()
+            c0.append(a)
+            c1.append(b)
+            child[s] = (a, b)
+        self.eng.pool_push(slots, c0, c1, [self.lower[s] for s in slots])
+        self.in_flight += len(slots)
 
     # -- driver ---------------------------------------------------------------------------------
     def step(self, chunks=1):
@@ -263,21 +364,28 @@ class StreamSearch(object):
         # (a full synchronisation point for tools that hook the runtime; costs one bubble in 64 chunks)
         self._rounds = getattr(self, "_rounds", 0) + 1
         dg, self.active, left = self.eng.pool_collect(keep_in_flight=0 if self._rounds % 64 == 0 else 1)
-        for g in dg:
-            self._absorb(g)
+        self._absorb_all(dg)
         self._push(left)
         alive = len(self.open) + self.in_flight
         if alive == 0 or (self.in_flight == 0 and self.open):
             # the tree may be closed -- or the host has leaves it could not push: drain the launch in flight first
             dg, self.active, left = self.eng.pool_collect(keep_in_flight=0)
-            for g in dg:
-                self._absorb(g)
+            self._absorb_all(dg)
             self._push(left)
             alive = len(self.open) + self.in_flight
             if self.in_flight == 0 and self.open:
                 raise MemoryError("leaf pool exhausted: %d open leaves, %d free slots of %d (raise `capacity`)"
                                   % (len(self.open), len(self.free), self.capacity))
         return alive
+
+    def _absorb_all(self, dg):
+        rows = dg.tolist()  # one conversion per collect: tuples of Python scalars
+        if self.observer is None:
+            for g in rows:
+                self._absorb(g)
+        else:
+            for k, g in enumerate(rows):
+                self._absorb(g, dg[k])
 
     def run(self, chunks=1, max_nodes=None):
         w = self.work
