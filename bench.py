@@ -383,7 +383,9 @@ def main():
             self.hs = search.HostedSearch(model)
             self.sh = None
             if world > 1 or (launched and os.environ.get("MIOSQP_FORCE_EXCHANGE") == "1"):
-                self.sh = dist.ShardedStream(model, comm, search=self.hs, exchange_every=1,
+                # one leaf per rank ends the replicated start-up (a node-at-a-time rank needs one; dry ranks are fed
+                # at the exchanges)
+                self.sh = dist.ShardedStream(model, comm, search=self.hs, exchange_every=1, ramp_leaves=1,
                                              step_kwargs=dict(nodes=10 ** 9 if budget else args.wave, budget=budget))
             self._g0 = 0
 
