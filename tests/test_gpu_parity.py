@@ -1221,6 +1221,32 @@ def test_hosted_search_on_every_engine_form(form):
             hs.run()
 
 
+def test_hosted_search_survives_a_called_off_cooperative_launch(monkeypatch):
+    """The hosted loop with the fault of test_cooperative_solver_reports_a_missing_workgroup_and_recovers: the first
+    node's cooperative launch is called off, the SAME node is redone in the two-kernel form, the search goes on there and
+    ends like a search on an engine that never was cooperative."""
+    from miosqp_amd import bnb
+    pr = problems.random_miqp(60, 120, 30, seed=11)
+    st = dict(problems.BNB_SETTINGS, device_tree=False)
+    monkeypatch.setenv("MIOSQP_COOP_NAP", "12")
+    monkeypatch.setenv("MIOSQP_COOP_DBG", "64")
+    bad = bnb.MIOSQP()
+    bad.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS, coop=1, resident=0))
+    monkeypatch.delenv("MIOSQP_COOP_DBG")
+    ref = bnb.MIOSQP()
+    ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS, coop=0, resident=0))
+    assert bad.work.solver.factor_stats()["coop"] is True
+    r0, r1 = ref.solve(), bad.solve()
+    fs = bad.work.solver.factor_stats()
+    assert fs["coop"] is False and fs["coop_fallbacks"] >= 1
+    assert getattr(bad.work, "_hosted", None) is not None and getattr(ref.work, "_hosted", None) is not None
+    assert (r1.status, bad.work.iter_num, bad.work.osqp_iter) == (r0.status, ref.work.iter_num, ref.work.osqp_iter)
+    assert r1.upper_glob == r0.upper_glob
+    np.testing.assert_array_equal(r1.x, r0.x)
+
+
 def test_hosted_search_at_config2_size():
     """Config 2 (n=500, m=1000, p=250) through the hosted search in the engine's cooperative form: the first 40 nodes
     equal the Python loop's (nodes, iterations, incumbent)."""
