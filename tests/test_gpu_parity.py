@@ -814,6 +814,58 @@ def test_engine_form_boundaries(oracle_mod, n, m, p):
     assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL
 
 
+@pytest.mark.parametrize("n,m,p,seed", [(60, 120, 30, 1), (300, 600, 124, 2), (300, 600, 125, 3), (500, 1000, 250, 0), (600, 1100, 290, 4)])
+def test_termination_test_on_tester_workgroups_equals_the_test_inside_the_grid(n, m, p, seed, monkeypatch):
+    """k_coop with its termination test on tester workgroups (decision picked up `lag` iterations later, the owners'
+    iterates of the test iteration restored) against the same solver with the test inside the grid
+    (MIOSQP_COOP_TESTERS=0): same status, same iteration count, bitwise the same x and y -- the iterates do not depend on
+    where the norms are reduced -- for several lags, both register layouts (n+M <= 1024 and above), a node that hits
+    the iteration limit between two tests, and an infeasible node."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    A, l, u = problems.extended(pr)
+    monkeypatch.setenv("MIOSQP_COOP_TESTERS", "0")
+    ref = qp.OSQP()
+    ref.setup(pr["P"], pr["q"], A, l, u, coop=1, resident=0, **problems.QP_SETTINGS)
+    monkeypatch.delenv("MIOSQP_COOP_TESTERS")
+    rng = np.random.RandomState(seed)
+    x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(A.shape[0])
+    ref.set_integer_rows(pr["i_idx"], m)
+    l2, u2 = l.copy(), u.copy()
+    k = m + p // 2
+    l2[k], u2[k] = 1.0, 1.0   # one binary fixed
+    l3, u3 = l.copy(), u.copy()
+    l3[:m] = u3[:m] = 5.0     # every general row pinned outside its reach: (very likely) primal infeasible
+    cases = [(l, u), (l2, u2), (l3, u3)]
+    want = [ref.solve_node(a, b, x0, y0) for a, b in cases]
+    for lag in (3, 12, 20):
+        monkeypatch.setenv("MIOSQP_COOP_LAG", str(lag))
+        g = qp.OSQP()
+        g.setup(pr["P"], pr["q"], A, l, u, coop=1, resident=0, **problems.QP_SETTINGS)
+        g.set_integer_rows(pr["i_idx"], m)
+        assert g.factor_stats()["coop"]
+        for (a, b), w in zip(cases, want):
+            r = g.solve_node(a, b, x0, y0)
+            assert (r.status_val, r.iter) == (w.status_val, w.iter), (lag, w.status_val, w.iter)
+            np.testing.assert_array_equal(r.x, w.x)
+            np.testing.assert_array_equal(r.y, w.y)
+    # the iteration limit falls between two tests: the last test is the final one, waited for at once
+    monkeypatch.setenv("MIOSQP_COOP_LAG", "12")
+    for max_iter in (60, 101, 110):
+        out = []
+        for testers in ("0", None):
+            if testers is not None:
+                monkeypatch.setenv("MIOSQP_COOP_TESTERS", testers)
+            g = qp.OSQP()
+            g.setup(pr["P"], pr["q"], A, l, u, coop=1, resident=0, **dict(problems.QP_SETTINGS, max_iter=max_iter))
+            g.set_integer_rows(pr["i_idx"], m)
+            out.append(g.solve_node(l, u, x0, y0))
+            if testers is not None:
+                monkeypatch.delenv("MIOSQP_COOP_TESTERS")
+        assert (out[0].status_val, out[0].iter) == (out[1].status_val, out[1].iter)
+        np.testing.assert_array_equal(out[0].x, out[1].x)
+
+
 def test_randomised_sweep_over_shapes_forms_and_bounds(oracle_mod):
     """60 small random instances: random shape and density, random engine form, random warm start, bounds
     randomly tightened (some relaxations become infeasible): status, iteration count and solution equal
