@@ -1299,6 +1299,33 @@ def test_hosted_search_survives_a_called_off_cooperative_launch(monkeypatch):
     np.testing.assert_array_equal(r1.x, r0.x)
 
 
+def test_hosted_search_random_sweep():
+    """60 random small MIQPs (random shape, density, exploration rule, engine form): the hosted loop and the Python loop
+    visit the same number of nodes, spend the same iterations and end with the same incumbent value."""
+    from miosqp_amd import bnb
+    rng = np.random.RandomState(123)
+    done = 0
+    for trial in range(60):
+        n = int(rng.randint(8, 70)); m = int(rng.randint(5, 120)); p = int(rng.randint(2, max(3, n // 2)))
+        rule = int(rng.randint(0, 2)); seed = int(rng.randint(0, 10 ** 6))
+        dens = float(rng.choice([0.3, 0.7, 1.0]))
+        pr = problems.random_miqp(n, m, p, density=dens, seed=seed)
+        st = dict(problems.BNB_SETTINGS, tree_explor_rule=rule, device_tree=False, max_iter_bb=400)
+        qs = dict(problems.QP_SETTINGS, resident=int(rng.choice([0, -1])))
+        out = []
+        for hosted in (False, True):
+            mdl = bnb.MIOSQP()
+            mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                      dict(st, device_search=hosted), dict(qs))
+            r = mdl.solve()
+            out.append((r.status, mdl.work.iter_num, mdl.work.osqp_iter, r.upper_glob))
+            mdl.work.solver.close()
+        assert out[0][:3] == out[1][:3], (n, m, p, rule, seed, dens, out)
+        assert out[0][3] == out[1][3] or abs(out[0][3] - out[1][3]) <= 1e-9 * max(1.0, abs(out[0][3])), (seed, out)
+        done += 1
+    assert done == 60
+
+
 def test_hosted_search_at_config2_size():
     """Config 2 (n=500, m=1000, p=250) through the hosted search in the engine's cooperative form: the first 40 nodes
     equal the Python loop's (nodes, iterations, incumbent)."""
