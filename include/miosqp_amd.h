@@ -310,6 +310,33 @@ int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, 
 /* debug: shader cycles and 100 MHz ticks recorded by the last LDS-resident launch */
 int miosqp_qp_debug_clock(miosqp_qp_engine *e, double *cycles, double *ticks);
 
+/* ---- the host side of the streaming search, compiled ------------------------------------------------------
+ * What miosqp_amd/stream.py: StreamSearch does per round -- push the next leaves in the exploration rule's order
+ * (workspace.py:128-149), launch, collect the launch before, bound_and_branch on every digest (workspace.py:282-334),
+ * prune -- as one call per `rounds` rounds on top of miosqp_qp_pool_*: the same exploration order and node counts,
+ * no interpreter between two chunks (several pools on several host threads stay bound by the device).  The value of
+ * an incumbent found by the rounding heuristic is the device's.  Needs set_integer_rows + set_root. */
+typedef struct miosqp_stream_info {
+  int64_t alive;        /* leaves open on the host, waiting in the ring or being solved (0: the tree is closed) */
+  int64_t open_leaves, in_flight, free_slots;
+  int64_t nodes, osqp_iter, chunks, dropped;   /* totals since the driver was created */
+  int32_t improved;     /* 1: the incumbent improved during this call */
+  int32_t active;       /* columns holding a node after the last refill seen */
+  double upper_glob;
+} miosqp_stream_info;
+
+/* creates the pool if there is none; ring_margin 0 = max(32, columns / 2) */
+int miosqp_qp_stream_create(miosqp_qp_engine *e, int32_t capacity, int32_t columns, int32_t ring_margin);
+int miosqp_qp_stream_begin(miosqp_qp_engine *e);
+int miosqp_qp_stream_add_leaf(miosqp_qp_engine *e, const double *l_int, const double *u_int, const double *x0,
+                              const double *y0, int32_t depth, double lower);
+int miosqp_qp_stream_take_leaf(miosqp_qp_engine *e, double *l_int, double *u_int, double *x0, double *y0, int32_t *depth,
+                               double *lower);
+int miosqp_qp_stream_set_incumbent(miosqp_qp_engine *e, double upper, const double *x);
+int miosqp_qp_stream_get_incumbent(miosqp_qp_engine *e, double *upper, double *x);
+int miosqp_qp_stream_step(miosqp_qp_engine *e, int32_t tree_explor_rule, int32_t chunks, int32_t rounds,
+                          int64_t max_nodes, miosqp_stream_info *info);
+
 #ifdef __cplusplus
 }
 #endif

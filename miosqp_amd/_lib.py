@@ -42,6 +42,12 @@ class SearchInfo(C.Structure):
                 ("device_time", C.c_double), ("run_time", C.c_double)]
 
 
+class StreamInfo(C.Structure):
+    _fields_ = [("alive", C.c_int64), ("open_leaves", C.c_int64), ("in_flight", C.c_int64), ("free_slots", C.c_int64),
+                ("nodes", C.c_int64), ("osqp_iter", C.c_int64), ("chunks", C.c_int64), ("dropped", C.c_int64),
+                ("improved", C.c_int32), ("active", C.c_int32), ("upper_glob", C.c_double)]
+
+
 class PoolDigest(C.Structure):
     _fields_ = [("slot", C.c_int32), ("status_val", C.c_int32), ("iter", C.c_int32), ("int_inf", C.c_int32),
                 ("nextvar", C.c_int32), ("reserved", C.c_int32), ("lower", C.c_double), ("heur_viol", C.c_double),
@@ -68,6 +74,13 @@ SYMBOLS = {
     "miosqp_qp_search_set_incumbent": (C.c_int, [C.c_void_p, C.c_double, dp]),
     "miosqp_qp_search_get_incumbent": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), dp]),
     "miosqp_qp_search_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.POINTER(SearchInfo)]),
+    "miosqp_qp_stream_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "miosqp_qp_stream_begin": (C.c_int, [C.c_void_p]),
+    "miosqp_qp_stream_add_leaf": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.c_int32, C.c_double]),
+    "miosqp_qp_stream_take_leaf": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "miosqp_qp_stream_set_incumbent": (C.c_int, [C.c_void_p, C.c_double, dp]),
+    "miosqp_qp_stream_get_incumbent": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), dp]),
+    "miosqp_qp_stream_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(StreamInfo)]),
     "miosqp_qp_solve_batch": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp,
                                         C.POINTER(Info)]),
     "miosqp_qp_solve_tree": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.c_double, dp, C.c_int32, C.c_int32, dp,

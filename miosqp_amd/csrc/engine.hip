@@ -28,6 +28,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <queue>
+#include <deque>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -191,6 +193,7 @@ struct Dev {
 #include "host.inc"  // host side: engine object, allocation, launches, graph capture, solve loops
 #include "host_pool.inc"  // host side of the leaf pool (C ABI miosqp_qp_pool_*)
 #include "host_search.inc"  // node-at-a-time branch and bound driven from the host in C++ (C ABI miosqp_qp_search_*)
+#include "host_stream.inc"  // the host side of the streaming search in C++ (C ABI miosqp_qp_stream_*)
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -244,6 +247,7 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   drop_stream_graph(e);
   for (hipEvent_t ev : e->ev_pool)
     if (ev) hipEventDestroy(ev);
+  if (e->sdriver) delete static_cast<StreamDriver *>(e->sdriver);
   if (e->search) {
     NodeSearch *S = static_cast<NodeSearch *>(e->search);
     if (S->dg) hipHostFree(S->dg);
@@ -675,6 +679,7 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
   for (int k = 0; k < n_int; k++)
     if (i_idx[k] < 0 || i_idx[k] >= e->n) return MIOSQP_EARG;
   if (n_int) HIPCHK(hipMemcpy((void *)e->d.i_idx, i_idx, sizeof(int) * n_int, hipMemcpyHostToDevice));
+  e->h_iidx.assign(i_idx, i_idx + n_int);  // host copy (the streaming driver rounds an incumbent's integer entries)
   {
     std::vector<int> pos(e->n, -1);
     for (int k = 0; k < n_int; k++) pos[i_idx[k]] = k;

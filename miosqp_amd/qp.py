@@ -248,6 +248,45 @@ class OSQP(object):
                                               C.byref(info)), "search_run")
         return info
 
+    # -- the host side of the streaming search, compiled (miosqp_qp_stream_*) ---------------------------
+    def stream_create(self, capacity, columns, ring_margin=0):
+        _check(self._lib.miosqp_qp_stream_create(self._h, int(capacity), int(columns), int(ring_margin)), "stream_create")
+        self._stream_info = _lib.StreamInfo()
+
+    def stream_begin(self):
+        _check(self._lib.miosqp_qp_stream_begin(self._h), "stream_begin")
+
+    def stream_add_leaf(self, l_int, u_int, x0, y0, depth, lower):
+        k = len(l_int)
+        rc = _check(self._lib.miosqp_qp_stream_add_leaf(
+            self._h, _lib.as_d(_f64(l_int, k, "l_int")), _lib.as_d(_f64(u_int, k, "u_int")),
+            _lib.as_d(_f64(x0, self.n, "x0")), _lib.as_d(_f64(y0, self.m, "y0")), int(depth), float(lower)),
+            "stream_add_leaf")
+        if rc == 1:
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+
+    def stream_take_leaf(self, n_int):
+        l, u, x, y = np.empty(n_int), np.empty(n_int), np.empty(self.n), np.empty(self.m)
+        depth, lower = C.c_int32(), C.c_double()
+        rc = _check(self._lib.miosqp_qp_stream_take_leaf(self._h, _lib.as_d(l), _lib.as_d(u), _lib.as_d(x), _lib.as_d(y),
+                                                         C.byref(depth), C.byref(lower)), "stream_take_leaf")
+        return None if rc == 1 else (l, u, x, y, depth.value, lower.value)
+
+    def stream_set_incumbent(self, upper, x):
+        _check(self._lib.miosqp_qp_stream_set_incumbent(self._h, float(min(upper, 1.7e308)),
+                                                        _lib.as_d(_f64(x, self.n, "x"))), "stream_set_incumbent")
+
+    def stream_get_incumbent(self):
+        upper, x = C.c_double(), np.empty(self.n)
+        _check(self._lib.miosqp_qp_stream_get_incumbent(self._h, C.byref(upper), _lib.as_d(x)), "stream_get_incumbent")
+        return (upper.value, x) if upper.value < 1.7e308 else (float("inf"), None)
+
+    def stream_step(self, tree_explor_rule, chunks=1, rounds=1, max_nodes=0):
+        info = self._stream_info
+        _check(self._lib.miosqp_qp_stream_step(self._h, int(tree_explor_rule), int(chunks), int(rounds), int(max_nodes),
+                                               C.byref(info)), "stream_step")
+        return info
+
     # -- device-resident leaf pool + streaming batch (miosqp_qp_pool_*) ------------------------------
     POOL_PRUNED = -100
 

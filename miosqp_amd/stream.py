@@ -399,6 +399,95 @@ class StreamSearch(object):
         return bnb.Results(w.x, w.upper_glob, w.run_time, w.status, w.osqp_solve_time, w.osqp_iter_avg)
 
 
+class NativeStreamSearch(object):
+    """StreamSearch with its per-round work in the C++ host library (miosqp_qp_stream_*, csrc/host_stream.inc): the
+    same exploration order and node counts, no interpreter between two chunks.  Same interface; no observer (use
+    StreamSearch for that).  What differs: the value of an incumbent found by the rounding heuristic is the device's
+    (StreamSearch recomputes it with numpy; ~1e-12 relative apart)."""
+
+    def __init__(self, model, columns=256, capacity=None, ring_margin=None, rounds=1):
+        self.model, self.work = model, model.work
+        w = self.work
+        self.eng = w.solver
+        if not hasattr(self.eng, "stream_create"):
+            raise TypeError("the native streaming search needs the HIP engine (miosqp_amd.qp)")
+        if w.settings['tree_explor_rule'] not in (0, 1):
+            raise ValueError('Tree exploring strategy not recognized')
+        self.columns, self.p, self.rounds = int(columns), w.data.n_int, int(rounds)
+        slot_bytes = 8 * (w.data.n + w.data.m + 3 * self.p + 1)
+        self.capacity = int(capacity) if capacity else int(max(4096, min(65536, (8 << 30) // slot_bytes)))
+        if not getattr(self.eng, "_sdriver_made", False):
+            if getattr(self.eng, "_pool_made", False):
+                self.capacity = self.eng._pool_capacity
+            self.eng.stream_create(self.capacity, self.columns, int(ring_margin or 0))
+            self.eng._sdriver_made = self.eng._pool_made = True
+            self.eng._pool_capacity = self.capacity
+        self.capacity = self.eng._pool_capacity
+        self.nodes = self.iters = self.chunks = self.dropped = 0
+        self._open = self.in_flight = 0
+        self._free = self.capacity
+        self.begin_instance()
+
+    open = property(lambda self: range(self._open))
+    free = property(lambda self: range(self._free))
+
+    def _sync(self, info):
+        w = self.work
+        w.iter_num += info.nodes - self.nodes
+        w.osqp_iter += info.osqp_iter - self.iters
+        self.nodes, self.iters, self.chunks, self.dropped = info.nodes, info.osqp_iter, info.chunks, info.dropped
+        self._open, self.in_flight, self._free = info.open_leaves, info.in_flight, info.free_slots
+        if info.improved:
+            w.upper_glob, w.x = self.eng.stream_get_incumbent()
+        return info.alive
+
+    def begin_instance(self, seed_root=True):
+        w = self.work
+        self.eng.stream_begin()
+        self._open, self.in_flight, self._free = 0, 0, self.capacity
+        if seed_root:
+            root = w.leaves[0] if w.leaves else w._make_root()
+            self.add_leaf(root.l[-self.p:], root.u[-self.p:], root.x, root.y, 0, root.lower)
+        w.leaves = []
+        if np.isfinite(w.upper_glob):
+            self.eng.stream_set_incumbent(w.upper_glob, w.x)
+
+    def add_leaf(self, l_int, u_int, x0, y0, depth, lower):
+        self.eng.stream_add_leaf(l_int, u_int, x0, y0, depth, lower)
+        self._open += 1
+        self._free -= 1
+
+    def givable(self):
+        return self._open
+
+    def give_leaf(self):
+        rec = self.eng.stream_take_leaf(self.p)
+        self._sync(self.eng.stream_step(self.work.settings['tree_explor_rule'], 1, 0))  # (no round: the counts)
+        return rec
+
+    def adopt_incumbent(self, value, x):
+        w = self.work
+        if value < w.upper_glob:
+            w.upper_glob = value
+            w.x = np.array(x, dtype=float)
+            self.eng.stream_set_incumbent(value, w.x)
+
+    def step(self, chunks=1, rounds=None, max_nodes=0):
+        return self._sync(self.eng.stream_step(self.work.settings['tree_explor_rule'], chunks,
+                                               self.rounds if rounds is None else rounds, max_nodes))
+
+    def run(self, chunks=1, max_nodes=None):
+        w = self.work
+        cap = w.settings['max_iter_bb'] if max_nodes is None else max_nodes
+        alive = 1
+        while alive > 0 and self.nodes + 1 < cap:
+            alive = self.step(chunks, rounds=64, max_nodes=cap)
+        w.osqp_iter_avg = w.osqp_iter / float(max(1, w.iter_num))
+        w.get_return_status(finished=(alive == 0))
+        w.get_return_solution()
+        return bnb.Results(w.x, w.upper_glob, w.run_time, w.status, w.osqp_solve_time, w.osqp_iter_avg)
+
+
 class MultiPoolSearch(object):
     """Several streaming pools on ONE GPU, one tree.  `pools` engines of the same MIQP (each its own stream, batch
     and leaf pool; the factor is set up once per engine) are driven by `pools` host threads and share the tree like

@@ -1130,6 +1130,53 @@ def test_streaming_search_on_the_leaf_pool(n, m, p, seed, cols, fold):
     np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
 
 
+@pytest.mark.parametrize("n,m,p,seed,cols,rule", [(30, 150, 15, 4, 64, 1), (50, 100, 25, 2, 128, 1), (40, 60, 20, 7, 64, 0),
+                                                   (60, 120, 40, 3, 64, 1)])
+def test_native_stream_driver_equals_the_python_driver(n, m, p, seed, cols, rule):
+    """miosqp_qp_stream_* (the host side of the streaming search compiled into the library) against stream.StreamSearch:
+    the same logic, the same optimum, every slot returned -- over two MIQPs on one factor; leaves taken out and put
+    back.  (Node counts are close, not equal: how many leaves a round pushes depends on how far the launch in flight
+    has got when the host looks, for either driver.)"""
+    from miosqp_amd import bnb, stream
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6, tree_explor_rule=rule)
+    mods = []
+    for _ in range(2):
+        mdl = bnb.MIOSQP()
+        mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+                  dict(problems.QP_SETTINGS, max_batch=cols))
+        mods.append(mdl)
+    py = stream.StreamSearch(mods[0], columns=cols, capacity=4096)
+    cc = stream.NativeStreamSearch(mods[1], columns=cols, capacity=4096)
+    ii = pr["i_idx"]
+    rng = np.random.RandomState(seed)
+    for inst in range(2):
+        r0, r1 = py.run(), cc.run()
+        assert r1.status == r0.status == bnb.MI_SOLVED
+        assert 0.4 * py.nodes <= cc.nodes <= 2.5 * py.nodes and cc.chunks >= 1
+        assert abs(r1.upper_glob - r0.upper_glob) <= 1e-9 * max(1.0, abs(r0.upper_glob))
+        np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
+        assert len(cc.free) == cc.capacity and len(cc.open) == 0 and cc.in_flight == 0
+        q2 = rng.randn(n)
+        for mdl in mods:
+            mdl.update_vectors(q=q2)
+        py.begin_instance()
+        cc.begin_instance()
+    # a few rounds, every open leaf out and in again, then to the end: still the optimum of the Python driver
+    for _ in range(3):
+        cc.step()
+    recs = [cc.give_leaf() for _ in range(cc.givable())]
+    assert cc.givable() == 0
+    for rec in recs:
+        cc.add_leaf(*rec)
+    assert cc.givable() == len(recs)
+    r0, r1 = py.run(), cc.run()
+    assert r1.status == r0.status
+    assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+    np.testing.assert_array_equal(r1.x[ii], r0.x[ii])
+    assert len(cc.free) == cc.capacity
+
+
 def test_sharded_stream_on_the_real_pool_one_rank():
     """dist.ShardedStream with one rank (LocalComm): replicated ramp-up on the host, the leaves written into the
     device pool with explicit vectors (add_leaf), then the stream -- the sequential optimum, every slot returned;
