@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--stream-chunks", type=int, default=600, help="streaming leg: timed chunks")
     ap.add_argument("--pools", type=int, default=2,
                     help="streaming leg, one rank: also run the tree on this many pools of the one GPU (1 = skip)")
+    ap.add_argument("--stream-driver", choices=["native", "python"], default="native",
+                    help="host side of the streaming search: compiled into the library (miosqp_qp_stream_*) or stream.StreamSearch")
     ap.add_argument("--stream-exchange", type=int, default=4,
                     help="streaming leg with more than one rank: chunks between two exchanges")
     ap.add_argument("--no-large-leg", action="store_true",
@@ -499,12 +501,14 @@ def main():
         # every rank streams its own leaf pool and the ranks meet every few chunks (dist.ShardedStream)
         from miosqp_amd import stream as stream_mod
         next_instance()
+        native = args.stream_driver == "native"
         if world == 1:
-            ss = stream_mod.StreamSearch(model, columns=args.batch_width)
+            ss = (stream_mod.NativeStreamSearch if native else stream_mod.StreamSearch)(model, columns=args.batch_width)
             sh = None
             stepper, restart = ss.step, ss.begin_instance
         else:
-            sh = dist.ShardedStream(model, comm, columns=args.batch_width, exchange_every=args.stream_exchange)
+            sh = dist.ShardedStream(model, comm, columns=args.batch_width, exchange_every=args.stream_exchange,
+                                    search=stream_mod.NativeStreamSearch(model, columns=args.batch_width) if native else None)
             ss = sh.ss
             stepper, restart = sh.step, sh.begin_instance
 
@@ -529,7 +533,7 @@ def main():
             tb = torch.tensor([dts], dtype=torch.float64, device=comm.device)
             td.all_reduce(tb, op=td.ReduceOp.MAX)
             dts = float(tb.item())
-        batched = dict(width=args.batch_width, form="stream on the device-resident leaf pool" +
+        batched = dict(width=args.batch_width, form="stream on the device-resident leaf pool" + (", host side in the library" if native else ", host side in Python") +
                        ("" if world == 1 else ", one pool per rank, incumbent + dry-rank feed every %d chunks"
                         % args.stream_exchange),
                        chunks=ss.chunks - c2, nodes=float(tots[1]),
@@ -556,7 +560,7 @@ def main():
                 mdl.update_vectors(q=r.randn(cfg["n"]), l=-2 + r.rand(m_orig), u=2 + r.rand(m_orig))
 
             mp = stream_mod.MultiPoolSearch(make_model, pools=args.pools, columns=args.batch_width,
-                                            exchange_every=args.stream_exchange)
+                                            exchange_every=args.stream_exchange, driver=args.stream_driver)
             mp.steps(args.stream_warmup, reroot)
             torch.cuda.synchronize()
             a0 = [(sh_.ss.nodes, sh_.ss.iters) for sh_ in mp.sh]

@@ -292,10 +292,15 @@ class OSQP(object):
 
     def pool_create(self, capacity, columns):
         _check(self._lib.miosqp_qp_pool_create(self._h, int(capacity), int(columns)), "pool_create")
-        self._dg = (_lib.PoolDigest * 8192)()
-        self._dg_np = np.frombuffer(self._dg, dtype=np.dtype(
-            [("slot", "i4"), ("status_val", "i4"), ("iter", "i4"), ("int_inf", "i4"), ("nextvar", "i4"), ("reserved", "i4"),
-             ("lower", "f8"), ("heur_viol", "f8"), ("heur_obj", "f8"), ("pri_res", "f8"), ("dua_res", "f8")]))
+
+    def _digest_buffer(self):
+        if getattr(self, "_dg", None) is None:
+            self._dg = (_lib.PoolDigest * 8192)()
+            self._dg_np = np.frombuffer(self._dg, dtype=np.dtype(
+                [("slot", "i4"), ("status_val", "i4"), ("iter", "i4"), ("int_inf", "i4"), ("nextvar", "i4"),
+                 ("reserved", "i4"), ("lower", "f8"), ("heur_viol", "f8"), ("heur_obj", "f8"), ("pri_res", "f8"),
+                 ("dua_res", "f8")]))
+        return self._dg
 
     def pool_reset(self):
         _check(self._lib.miosqp_qp_pool_reset(self._h), "pool_reset")
@@ -332,7 +337,7 @@ class OSQP(object):
         """Waits until at most `keep_in_flight` launches are still running; returns (digests as a numpy record
         array (a copy), active columns, ready-ring entries not yet taken)."""
         n, act, left = C.c_int32(), C.c_int32(), C.c_int64()
-        _check(self._lib.miosqp_qp_pool_collect(self._h, int(keep_in_flight), self._dg, 8192, C.byref(n),
+        _check(self._lib.miosqp_qp_pool_collect(self._h, int(keep_in_flight), self._digest_buffer(), 8192, C.byref(n),
                                                 C.byref(act), C.byref(left)), "pool_collect")
         return self._dg_np[:n.value].copy(), act.value, left.value
 

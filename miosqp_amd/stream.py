@@ -500,8 +500,14 @@ class MultiPoolSearch(object):
 
     make_model: () -> a set-up bnb.MIOSQP (called `pools` times; every model must describe the same problem)."""
 
-    def __init__(self, make_model, pools=2, columns=256, exchange_every=4, capacity=None):
+    def __init__(self, make_model, pools=2, columns=256, exchange_every=4, capacity=None, driver="python"):
+        """driver: "python" -- every pool's rounds in StreamSearch (one interpreter, `pools` threads taking turns on its
+        lock between two chunks); "native" -- in NativeStreamSearch (the C++ library runs `exchange_every` rounds per
+        call without the lock; the threads only meet the interpreter for the exchange)."""
         from miosqp_amd import dist
+        if driver not in ("python", "native"):
+            raise ValueError("driver: 'python' or 'native'")
+        self.driver = driver
         self.pools = int(pools)
         self.models = [make_model() for _ in range(self.pools)]
         self.world = dist.ThreadWorld(self.pools)
@@ -534,8 +540,14 @@ class MultiPoolSearch(object):
 
     def _shard(self, k):
         if self.sh[k] is None:
-            self.sh[k] = self._dist.ShardedStream(self.models[k], self._dist.ThreadComm(self.world, k), columns=self.columns,
-                                                  exchange_every=self.exchange_every, capacity=self.capacity)
+            comm = self._dist.ThreadComm(self.world, k)
+            if self.driver == "native":
+                ns = NativeStreamSearch(self.models[k], columns=self.columns, capacity=self.capacity,
+                                        rounds=self.exchange_every)
+                self.sh[k] = self._dist.ShardedStream(self.models[k], comm, exchange_every=1, search=ns)
+            else:
+                self.sh[k] = self._dist.ShardedStream(self.models[k], comm, columns=self.columns,
+                                                      exchange_every=self.exchange_every, capacity=self.capacity)
         return self.sh[k]
 
     def update_vectors(self, q=None, l=None, u=None):
@@ -566,7 +578,8 @@ class MultiPoolSearch(object):
         same data on every pool -- and the search goes on.  Returns per-pool (nodes, iterations, chunks)."""
         def body(k):
             sh = self._shard(k)
-            for _ in range(count):
+            per_step = self.exchange_every if self.driver == "native" else 1
+            for _ in range(max(1, count // per_step)):
                 if sh.step() == 0:
                     if next_instance is None:
                         break

@@ -1414,9 +1414,11 @@ def test_sharded_hosted_search_one_rank():
     np.testing.assert_array_equal(w.x[pr["i_idx"]], r0.x[pr["i_idx"]])
 
 
-def test_two_pools_on_one_gpu_share_one_tree():
+@pytest.mark.parametrize("driver", ["python", "native"])
+def test_two_pools_on_one_gpu_share_one_tree(driver):
     """stream.MultiPoolSearch on the real engine: two pools (two engines, two host threads) close one tree with the
-    sequential optimum, every slot comes back, and a second MIQP reuses both."""
+    sequential optimum, every slot comes back, and a second MIQP reuses both -- with the rounds of each pool in
+    stream.StreamSearch and in the library (miosqp_qp_stream_*)."""
     from miosqp_amd import bnb, stream
     pr = problems.random_miqp(50, 100, 25, seed=2)
     st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6)
@@ -1429,7 +1431,7 @@ def test_two_pools_on_one_gpu_share_one_tree():
 
     seq = bnb.MIOSQP()
     seq.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st), dict(problems.QP_SETTINGS))
-    mp = stream.MultiPoolSearch(make, pools=2, columns=64, exchange_every=2)
+    mp = stream.MultiPoolSearch(make, pools=2, columns=64, exchange_every=2, driver=driver)
     ii = pr["i_idx"]
     rng = np.random.RandomState(3)
     for inst in range(2):
