@@ -409,6 +409,17 @@ def main():
         head = Head()
 
         def head_steps(count):
+            if head.sh is None:
+                # one rank: the `count` steps (one node relaxation each, --wave nodes with that flag) are asked of the
+                # library in as few calls as the trees allow -- the interpreter is not between two nodes
+                left = count * args.wave
+                while left > 0:
+                    before = head.hs.nodes
+                    alive = head.hs.step(left)
+                    left -= head.hs.nodes - before
+                    if alive == 0:
+                        next_instance(head)
+                return
             for _ in range(count):
                 if head.step() == 0:
                     next_instance(head)
@@ -594,7 +605,7 @@ def main():
             # from the HIP events around the launches of the timed region
             launches = max(1, nodes_here)
             us, by = 1e3 * loop_ms / launches, fs["bytes_per_iter"] * loop_iters / launches
-            kern.append(dict(kernel="k_coop", usec=round(us, 3), bytes=round(by), gbs=round(by / us * 1e-3, 1),
+            kern.append(dict(kernel="k_coop", usec=round(us, 3), bytes=round(by), gbs=round(by / max(us, 1e-9) * 1e-3, 1),
                              launches=launches, iterations_per_launch=round(loop_iters / launches, 1)))
             it_us, it_bytes = (0.0, 0.0) if args.no_probes else eng.time_kernel(4, 2000)
         else:
