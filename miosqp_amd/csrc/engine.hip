@@ -385,6 +385,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     int rc__ = dupload(e, vec, &d.field);                \
     if (rc__) { miosqp_qp_cleanup(e); return rc__; }     \
   } while (0)
+  upload_begin(e);
   UP(f.panel_by_var.ptr, pv_ptr); UP(f.panel_by_var.idx, pv_idx); UP(f.panel_by_var.val, pv_L); UP(f.At_val, pv_At);
   UP(f.panel_by_con.ptr, pc_ptr); UP(f.panel_by_con.idx, pc_idx); UP(f.panel_by_con.val, pc_L); UP(f.A_val, pc_A);
   if (actx.dLinv) {  // computed on the device and left there
@@ -398,6 +399,10 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   UP(f.Praw.ptr, pr_ptr); UP(f.Praw.idx, pr_idx); UP(f.Praw.val, pr_val);
   UP(e->sc.D, D); UP(e->sc.Dinv, Dinv); UP(e->sc.E, E); UP(e->sc.Einv, Einv);
 #undef UP
+  {
+    int rcu = upload_end(e);
+    if (rcu) { miosqp_qp_cleanup(e); return rcu; }
+  }
 #define AL(field, count)                                 \
   do {                                                   \
     int rc__ = dalloc(e, &d.field, (size_t)(count));     \
@@ -450,11 +455,14 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     const int want = want_fold;
     if (want && M > 0) {
       miosqp::build_folded(f, e->fo);
+      upload_begin(e);
       int rc = dupload(e, e->fo.rows, &d.f_rows);
       if (!rc) rc = dupload(e, e->fo.GmT, &d.f_GmT);
       if (!rc) rc = dupload(e, e->fo.Ad, &d.f_Ad);
       if (!rc) rc = dupload(e, e->fo.Atd, &d.f_Atd);
       if (!rc) rc = dupload(e, e->fo.Pd, &d.f_Pd);
+      if (!rc) rc = upload_end(e);
+      else e->up_on = false;
       d.ldm = e->fo.ldm;
       if (rc) { miosqp_qp_cleanup(e); return rc; }
       d.ldf = e->fo.ldf;
