@@ -253,6 +253,7 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
     if (S->dg) hipHostFree(S->dg);
     delete S;
   }
+  if (e->h_tree) hipHostFree(e->h_tree);
   if (e->h_ready) hipHostFree(e->h_ready);
   if (e->h_dg) hipHostFree(e->h_dg);
   if (e->h_pctl) hipHostFree(e->h_pctl);
@@ -870,13 +871,7 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
   memcpy(e->h_in + M, u, sizeof(double) * M);
   memcpy(e->h_in + 2 * (size_t)M, x0, sizeof(double) * n);
   memcpy(e->h_in + 2 * (size_t)M + n, y0, sizeof(double) * M);
-  HIPCHK(hipEventRecord(e->ev0, e->stream));
-  HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * (3 * (size_t)M + n), hipMemcpyHostToDevice, e->stream));
   const bool have_inc = x_inc0 != nullptr && upper0 < 1.7e308;
-  if (have_inc) {
-    memcpy(e->h_out, x_inc0, sizeof(double) * n);
-    HIPCHK(hipMemcpyAsync(e->ta.inc_x, e->h_out, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
-  }
   TreeArgs ta = e->ta;
   ta.rule = tree_explor_rule;
   ta.max_nodes = max_iter_bb;
@@ -888,22 +883,87 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     ta.TG2 = std::min(64, std::max(1, pow2_floor(RES_THREADS / (n + M))));
   }
   ta.upper0 = have_inc ? upper0 : 1.0 / 0.0;
-  if (wave) hipLaunchKernelGGL(k_tree_w, dim3(1), dim3(TW), 0, e->stream, e->d, ta);
-  else hipLaunchKernelGGL(k_tree, dim3(1), dim3(RES_THREADS), lds, e->stream, e->d, ta);
-  HIPCHK(hipMemcpyAsync(e->h_out, e->ta.inc_x, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
-  static_assert(sizeof(TreeOut) <= sizeof(Ctrl), "TreeOut travels through the pinned control block");
-  HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ta.out, sizeof(TreeOut), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipEventRecord(e->ev1, e->stream));
-  if (e->spin_wait) {
-    hipError_t q;
-    while ((q = hipEventQuery(e->ev1)) == hipErrorNotReady) {}
-    if (q != hipSuccess) HIPCHK(q);
-  } else {
-    HIPCHK(hipStreamSynchronize(e->stream));
-  }
-  const TreeOut *o = reinterpret_cast<const TreeOut *>(e->h_ctrl);
+  ta.done = nullptr;
+  const TreeOut *o = nullptr;
+  const double *x_found = nullptr;
   float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  if (wave) {
+    // The one-wavefront search reads the root straight from the pinned staging block and writes incumbent and
+    // outcome into coherent host memory, the completion word last: ONE launch and no copy per MIQP (three copies and
+    // two events around a 60-400 us kernel were 25 us).  Device time: the kernel's own 100 MHz stamps.
+    if (!e->h_tree) {
+      HIPCHK(hipHostMalloc((void **)&e->h_tree, sizeof(double) * ((size_t)n + 16), hipHostMallocCoherent));
+      memset(e->h_tree, 0, sizeof(double) * ((size_t)n + 16));
+    }
+    unsigned long long *done = e->h_tree;
+    TreeOut *out = reinterpret_cast<TreeOut *>(e->h_tree + 4);
+    double *inc = reinterpret_cast<double *>(e->h_tree + 16);
+    static_assert(sizeof(TreeOut) <= 12 * sizeof(unsigned long long), "TreeOut fits its place in h_tree");
+    __atomic_store_n(&done[0], 0ull, __ATOMIC_RELAXED);
+    if (have_inc) memcpy(inc, x_inc0, sizeof(double) * n);
+    Dev dp = e->d;
+    dp.raw_l = e->h_in;
+    dp.raw_u = e->h_in + M;
+    dp.raw_x = e->h_in + 2 * (size_t)M;
+    dp.raw_y = e->h_in + 2 * (size_t)M + n;
+    ta.inc_x = inc;
+    ta.out = out;
+    ta.done = done;
+    static unsigned long long *tree_prof = nullptr;  // debug (MIOSQP_TREE_PROF=1): ticks per phase, summed over launches
+    static const bool tree_prof_on = getenv("MIOSQP_TREE_PROF") != nullptr;
+    if (tree_prof_on && !tree_prof) {
+      HIPCHK(hipMalloc((void **)&tree_prof, 64));
+      HIPCHK(hipMemset(tree_prof, 0, 64));
+    }
+    if (tree_prof_on) dp.prof = tree_prof;
+    hipLaunchKernelGGL(k_tree_w, dim3(1), dim3(TW), 0, e->stream, dp, ta);
+    if (e->spin_wait) {
+      unsigned long long spins = 0;
+      while (__atomic_load_n(&done[0], __ATOMIC_ACQUIRE) == 0ull) {
+        if ((++spins & 0xfffff) == 0) {
+          const hipError_t q = hipStreamQuery(e->stream);
+          if (q != hipSuccess && q != hipErrorNotReady) HIPCHK(q);
+          if (q == hipSuccess && __atomic_load_n(&done[0], __ATOMIC_ACQUIRE) == 0ull) {
+            g_err = "solve_tree: the stream is idle and the outcome never arrived";
+            return MIOSQP_EHIP;
+          }
+        }
+      }
+    } else {
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    if (tree_prof_on) {
+      unsigned long long h[6];
+      HIPCHK(hipMemcpy(h, tree_prof, sizeof h, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[tree prof] cumulative us: prologue %.1f  iterations %.1f  tests %.1f  epilogue %.1f  branch %.1f\n",
+              h[0] / 100.0, h[1] / 100.0, h[2] / 100.0, h[3] / 100.0, h[4] / 100.0);
+    }
+    o = out;
+    x_found = inc;
+    ms = (float)(1e-5 * (double)(done[2] - done[1]));  // 100 MHz ticks -> ms
+  } else {
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d.raw_l, e->h_in, sizeof(double) * (3 * (size_t)M + n), hipMemcpyHostToDevice, e->stream));
+    if (have_inc) {
+      memcpy(e->h_out, x_inc0, sizeof(double) * n);
+      HIPCHK(hipMemcpyAsync(e->ta.inc_x, e->h_out, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+    }
+    hipLaunchKernelGGL(k_tree, dim3(1), dim3(RES_THREADS), lds, e->stream, e->d, ta);
+    HIPCHK(hipMemcpyAsync(e->h_out, e->ta.inc_x, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+    static_assert(sizeof(TreeOut) <= sizeof(Ctrl), "TreeOut travels through the pinned control block");
+    HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ta.out, sizeof(TreeOut), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    if (e->spin_wait) {
+      hipError_t q;
+      while ((q = hipEventQuery(e->ev1)) == hipErrorNotReady) {}
+      if (q != hipSuccess) HIPCHK(q);
+    } else {
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    o = reinterpret_cast<const TreeOut *>(e->h_ctrl);
+    x_found = e->h_out;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  }
   info->nodes = o->nodes;
   info->osqp_iter = o->osqp_iter;
   info->leaves_left = o->leaves_left;
@@ -914,7 +974,7 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
   info->lower_glob = o->lower_glob;
   info->device_time = 1e-3 * ms;
   info->run_time = wall() - t0;
-  if (o->found || have_inc) memcpy(x_out, o->found ? e->h_out : x_inc0, sizeof(double) * n);
+  if (o->found || have_inc) memcpy(x_out, o->found ? x_found : x_inc0, sizeof(double) * n);
   e->loop_ms += ms;
   e->loop_iters += o->osqp_iter;
   return 0;
