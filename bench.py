@@ -193,7 +193,9 @@ def mpc_leg(device, repeats=3):
     fs = eng.factor_stats()
     steps = repeats * len(recs)
     out = dict(workload="power_converter MPC N=3 (n=18, 45 rows), %d MPC steps replayed %d times" % (len(recs), repeats),
-               engine_form="LDS-resident single workgroup" if fs["resident"] else
+               engine_form=("one wavefront per tree, explicit KKT inverse in registers (k_tree_w)"
+                            if fs["resident"] and model.work.data.n + model.work.data.m + model.work.data.n_int <= 64
+                            else "LDS-resident single workgroup") if fs["resident"] else
                            "cooperative" if fs["coop"] else "multi-kernel",
                mpc_steps_per_s=round(steps / dt, 1), nodes_per_s=round(nodes / dt, 1),
                iters_per_s=round(iters / dt, 1), usec_per_node=round(1e6 * dt / max(1, nodes), 1),
