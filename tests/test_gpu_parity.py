@@ -5,8 +5,13 @@ to 1e-9 relative (inf-norm); a finished solve has the identical status and itera
 x, y within 1e-8 relative; node lower bounds within 1e-9 relative.  Both sides implement the
 frozen spec of DESIGN.md; differences are summation order and FMA contraction only.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from golden_cases import case_names, load_case, load_maxiter, run_case
 from miosqp_amd import problems
@@ -1500,3 +1505,47 @@ def test_whole_tree_in_one_launch_follows_the_reference_traces(name):
             np.testing.assert_allclose(res.x, exp["x"], rtol=0, atol=1e-7)
         else:
             assert not np.isfinite(res.upper_glob)
+
+
+def test_one_wavefront_tree_equals_the_workgroup_tree():
+    """k_tree_w (n + M <= 64: the search in ONE wavefront, explicit KKT inverse in registers, DPP row broadcasts)
+    against k_tree (one workgroup, product form in LDS; MIOSQP_TREE_WAVE=0) on a sweep of random small MIQPs, both
+    exploration rules: same status, node count, iteration count and incumbent.  Two processes: the switch is read
+    once per process."""
+    import json
+    import subprocess
+    script = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from miosqp_amd import bnb, problems, qp
+out = []
+for seed, (n, m, p) in enumerate([(6, 4, 3), (8, 10, 4), (10, 12, 5), (12, 20, 6), (14, 24, 7), (16, 28, 8), (9, 30, 9),
+                                  (18, 20, 9), (12, 8, 12), (20, 22, 10)]):
+    pr = problems.random_miqp(n, m, p, seed=100 + seed)
+    for rule in (0, 1):
+        model = bnb.MIOSQP(backend=qp)
+        model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                    dict(problems.BNB_SETTINGS, tree_explor_rule=rule), dict(problems.QP_SETTINGS))
+        res = model.solve()
+        assert not getattr(model.work, "_no_tree", False)
+        out.append(dict(case=[n, m, p, rule], status=res.status, nodes=int(model.work.iter_num), iters=int(model.work.osqp_iter),
+                        upper=float(res.upper_glob), x=[float(v) for v in np.atleast_1d(res.x)]))
+        model.work.solver.close()
+print("RESULT " + json.dumps(out))
+''' % ROOT
+    runs = []
+    for wave in ("1", "0"):
+        env = dict(os.environ, MIOSQP_TREE_WAVE=wave)
+        p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        runs.append(json.loads(line[7:]))
+    assert len(runs[0]) == len(runs[1]) == 20
+    for a, b in zip(*runs):
+        assert (a["case"], a["status"], a["nodes"], a["iters"]) == (b["case"], b["status"], b["nodes"], b["iters"])
+        if np.isfinite(a["upper"]):
+            assert abs(a["upper"] - b["upper"]) <= 1e-8 * max(1.0, abs(b["upper"]))
+            np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-7)
+        else:
+            assert not np.isfinite(b["upper"])
