@@ -481,6 +481,15 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         if (wantr && need <= 160 * 1024) {
           e->resident = true;
           e->res_lds = need;
+          if (n + M <= 192 && M > 0 && !(getenv("MIOSQP_RES_W") && atoi(getenv("MIOSQP_RES_W")) == 0)) {
+            // the explicit KKT inverse for the register-resident loop (res_admm_w, kernels_resident.inc)
+            d.ldw = (n + M + 7) & ~7;
+            double *Wd = nullptr;
+            rc = dalloc(e, &Wd, (size_t)(n + M) * d.ldw + 64);
+            if (!rc) rc = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
+            if (rc) { miosqp_qp_cleanup(e); return rc; }
+            d.W = Wd;
+          }
           HIPCHK(hipFuncSetAttribute((const void *)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)need));
           // lanes per row: as many as keep every row of a sweep in flight at once
@@ -841,14 +850,17 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
   const double t0 = wall();
   // n + M <= 64: the whole search in ONE wavefront on the explicit KKT inverse (k_tree_w); MIOSQP_TREE_WAVE=0 keeps k_tree
   const bool wave = n + M <= TW && !(getenv("MIOSQP_TREE_WAVE") && atoi(getenv("MIOSQP_TREE_WAVE")) == 0);
-  if (wave && !e->d.W) {  // an engine in the LDS-resident form has not built W / Kc yet
+  if (wave && !e->d.Kc) {  // an engine in the LDS-resident form has not built Kc (and perhaps W) yet
     Dev &d = e->d;
     const int N = n + M;
     d.ldw = (N + 7) & ~7;
-    double *Wd = nullptr, *Kc = nullptr;
-    int rcw = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
+    double *Wd = const_cast<double *>(d.W), *Kc = nullptr;
+    int rcw = 0;
+    if (!Wd) {
+      rcw = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
+      if (!rcw) rcw = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
+    }
     if (!rcw) rcw = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
-    if (!rcw) rcw = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
     if (rcw) return rcw;
     d.W = Wd;
     d.Kc = Kc;
