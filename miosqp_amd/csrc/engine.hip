@@ -198,6 +198,21 @@ struct Dev {
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+namespace {
+// the dynamic-LDS ceiling of a kernel is a property of (process, device, kernel): raised to the chip's 160 KB once instead of
+// at every set-up (the call costs ~40 us, a fifth of a small problem's set-up)
+hipError_t lds_limit_once(const void *fn, int which) {
+  static bool done[2][64] = {};
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess) return rc;
+  if (dev >= 0 && dev < 64 && done[which][dev]) return hipSuccess;
+  rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (rc == hipSuccess && dev >= 0 && dev < 64) done[which][dev] = true;
+  return rc;
+}
+}  // namespace
+
 extern "C" {
 
 const char *miosqp_qp_last_error(void) { return g_err.c_str(); }
@@ -490,8 +505,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
             if (rc) { miosqp_qp_cleanup(e); return rc; }
             d.W = Wd;
           }
-          HIPCHK(hipFuncSetAttribute((const void *)k_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)need));
+          HIPCHK(lds_limit_once((const void *)k_resident, 0));
           // lanes per row: as many as keep every row of a sweep in flight at once
           auto pow2_floor = [](int v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
           e->res_tg1 = std::min(64, std::max(1, pow2_floor(RES_THREADS / n)));
@@ -867,7 +881,7 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
   }
   if (!e->tree_ready) {
-    HIPCHK(hipFuncSetAttribute((const void *)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(lds_limit_once((const void *)k_tree, 1));
     int rc = dalloc(e, &e->ta.lf_lo, (size_t)TREE_CAP * p);
     if (!rc) rc = dalloc(e, &e->ta.lf_hi, (size_t)TREE_CAP * p);
     if (!rc) rc = dalloc(e, &e->ta.lf_x, (size_t)TREE_CAP * n);
