@@ -23,6 +23,7 @@ Extra legs in the same JSON line (none of them is part of `value`):
             HBM every iteration, two launches per iteration) -- what the north star's roofline is about
   config5   BASELINE configs[4]: n=5000, the bandwidth-bound single-node case
   config4   BASELINE configs[3]: the power-converter MPC sequence (40 MIQPs, n=18)
+  config1   BASELINE configs[0]: n=50 (the reference's CPU-runnable size), whole trees, with the CPU oracle beside it
   cpu_baseline  the reference's CPU path (real OSQP when importable, else the oracle) on this box's host cores
   python_loop   the headline workload with the reference's control flow unchanged (bnb.Workspace in Python driving
             miosqp_qp_solve_node); `value` itself runs the same loop compiled into the host library
@@ -42,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 KERNELS = ["k_panel_fwd", "k_tail_fwd", "k_tail_bwd", "k_panel_bwd"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-ALL_LEGS = ("batched", "stream", "config5", "config4", "cpu", "pyloop")
+ALL_LEGS = ("batched", "stream", "config5", "config4", "config1", "cpu", "pyloop")
 
 
 def pmc_traffic(kernel, tag=""):
@@ -209,6 +210,57 @@ def mpc_leg(device, repeats=3):
     return out
 
 
+def small_leg(seed, device, instances=40):
+    """BASELINE configs[0] (n=50, m=100, p=10: the reference's own CPU-runnable size): a sequence of MIQPs on one
+    factor (update_vectors like the reference's MPC loop), each tree closed by MIOSQP.solve() -- on this engine one
+    launch per tree (k_tree; its ADMM loop on the explicit KKT inverse in the workgroup's registers) -- and, beside
+    it, the same sequence on the CPU oracle (test infrastructure used as the CPU yardstick, one thread)."""
+    from miosqp_amd import bnb, problems
+    cfg = problems.CONFIGS["cfg1"]
+    prob = problems.random_miqp(**cfg, seed=seed)
+    res = {}
+    for name in ("hip", "cpu_oracle"):
+        backend = None
+        if name == "cpu_oracle":
+            from oracle import oracle
+            backend = oracle
+        model = bnb.MIOSQP(backend=backend) if backend is not None else bnb.MIOSQP()
+        qs = dict(problems.QP_SETTINGS)
+        if backend is None:
+            qs["device"] = device
+        model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"], prob["i_u"],
+                    dict(problems.BNB_SETTINGS), qs)
+        rng = np.random.RandomState(seed + 4242)
+        nodes = iters = 0
+        uppers = []
+        t0 = None
+        for k in range(instances + 3):
+            if k == 3:
+                t0 = time.perf_counter()  # three warm-up instances
+                nodes = iters = 0
+            model.update_vectors(q=rng.randn(cfg["n"]), l=-2 + rng.rand(cfg["m"]), u=2 + rng.rand(cfg["m"]))
+            r = model.solve()
+            nodes += model.work.iter_num - 1
+            iters += model.work.osqp_iter
+            if k >= 3:
+                uppers.append(float(r.upper_glob))
+        dt = time.perf_counter() - t0
+        res[name] = dict(miqps_per_s=round(instances / dt, 1), usec_per_miqp=round(1e6 * dt / instances, 1),
+                         nodes_per_s=round(nodes / dt, 1), iters_per_s=round(iters / dt, 1),
+                         nodes_per_miqp=round(nodes / instances, 2), iters_per_node=round(iters / max(1, nodes), 1))
+        res[name + "_uppers"] = uppers
+        if backend is None:
+            model.work.solver.close()
+    a, b = res.pop("hip_uppers"), res.pop("cpu_oracle_uppers")
+    same = all((not np.isfinite(x) and not np.isfinite(y)) or abs(x - y) <= 1e-6 * max(1.0, abs(y)) for x, y in zip(a, b))
+    return dict(workload="random_miqp n=50 m=100 p=10 density 0.7, %d MIQPs on one factor (update_vectors), whole trees"
+                         % instances, hip=res["hip"],
+                cpu_baseline=dict(res["cpu_oracle"], kind="port", cores=1,
+                                  note="oracle/qp_oracle.c (own CPU restatement, not OSQP), the same sequence"),
+                same_optima=bool(same),
+                speedup_over_one_host_core=round(res["hip"]["miqps_per_s"] / max(1e-9, res["cpu_oracle"]["miqps_per_s"]), 2))
+
+
 def cpu_baseline(prob, budget_s):
     """The reference's CPU path on this box's host cores, bounded to about `budget_s` seconds of the same tree.
     Probes `import osqp` first: if the real package is present the tree search runs on it
@@ -290,7 +342,7 @@ def main():
                     help="skip the back-to-back kernel timing launches (profiling runs: every dispatch of the hot "
                          "kernel is then a node relaxation of the timed workload)")
     ap.add_argument("--legs", default="all",
-                    help="comma list of extra legs to run: batched,stream,config5,config4,cpu ('none' = headline only)")
+                    help="comma list of extra legs to run: batched,stream,config5,config4,config1,cpu ('none' = headline only)")
     args = ap.parse_args()
     legs = set(ALL_LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     if args.no_cpu_baseline:
@@ -702,6 +754,8 @@ def main():
                 out["config5"] = large_leg(args.seed, local_rank)
             if "config4" in legs:
                 out["config4"] = mpc_leg(local_rank)
+            if "config1" in legs:
+                out["config1"] = small_leg(args.seed, local_rank)
         if world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
         print(json.dumps(out))

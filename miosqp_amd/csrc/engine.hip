@@ -502,8 +502,12 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
             double *Wd = nullptr;
             rc = dalloc(e, &Wd, (size_t)(n + M) * d.ldw + 64);
             if (!rc) rc = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
+            double *Kc = nullptr;  // dense [0 Abar ; Abar^T Pbar]: the rows of the termination test in the same form
+            if (!rc) rc = dalloc(e, &Kc, (size_t)(n + M) * d.ldw + 64);
             if (rc) { miosqp_qp_cleanup(e); return rc; }
             d.W = Wd;
+            d.Kc = Kc;
+            hipLaunchKernelGGL(k_build_kc, dim3((n + M + 255) / 256, n + M), dim3(256), 0, e->stream, d, Kc);
           }
           HIPCHK(lds_limit_once((const void *)k_resident, 0));
           // lanes per row: as many as keep every row of a sweep in flight at once
