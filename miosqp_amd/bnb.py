@@ -507,7 +507,7 @@ class MIOSQP(object):
         hs = getattr(work, '_hosted', None)
         root = work.leaves[0]
         if hs is None:
-            hs = work._hosted = search.HostedSearch(self)
+            hs = work._hosted = search.HostedSearch(self, owned=True)
         else:
             hs.begin_instance()
         alive = hs._open

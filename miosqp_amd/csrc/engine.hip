@@ -354,14 +354,18 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   {
     const double dens = M > 0 ? (double)Ap[n] / ((double)n * M) : 0.0;
     const double fold_bytes = 8.0 * ((double)n * (M + n) + (double)M * n);
-    const bool fits_lds = resident_lds_doubles(n, M) * sizeof(double) <= 150 * 1024;
+    const bool res_w_on = !(getenv("MIOSQP_RES_W") && atoi(getenv("MIOSQP_RES_W")) == 0);
+    const bool fits_lds = resident_lds_doubles(n, M, res_w_on && M > 0 && n + M <= RES_W_MAX) * sizeof(double) <= 150 * 1024;
     // the cooperative solver only needs the product form to build its explicit inverse from, whatever
     // the sparsity; it is preferred from n + M = 64 on (measured: equal to the LDS-resident workgroup
     // below 100, 1.8x at 160, 2.2x at 240)
     int coop_req = s->coop;
     if (const char *ev = getenv("MIOSQP_COOP")) coop_req = atoi(ev);
     const bool coop_fits = M > 0 && n + M <= 2048;
-    coop_pref = coop_fits && (coop_req == 1 || (coop_req < 0 && n + M >= 64)) && s->resident != 1;
+    // ... and from n + M = 193 on since the LDS-resident workgroup runs its loop on the explicit inverse in registers
+    // (res_admm_w: 0.9-1.4 us per iteration at n + M = 85-190 against 2.1-2.2 for the cooperative grid)
+    const bool res_w_here = res_w_on && M > 0 && n + M <= RES_W_MAX && s->resident != 0;
+    coop_pref = coop_fits && (coop_req == 1 || (coop_req < 0 && n + M >= 64 && !res_w_here)) && s->resident != 1;
     if (want_fold < 0)
       want_fold = (M > 0 && ((dens >= 0.30 && fold_bytes <= 4.0e9) || (fits_lds && s->resident != 0) || coop_pref)) ? 1 : 0;
   }
@@ -490,13 +494,14 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       e->tpr_fx = pick_tpr(0.5 * n);
       e->tpr_fc = pick_tpr((double)n);
       {
-        const size_t need = resident_lds_doubles(n, M) * sizeof(double);
+        const bool res_w = n + M <= RES_W_MAX && M > 0 && !(getenv("MIOSQP_RES_W") && atoi(getenv("MIOSQP_RES_W")) == 0);
+        const size_t need = resident_lds_doubles(n, M, res_w) * sizeof(double);
         int wantr = s->resident;
         if (wantr < 0) wantr = (need <= 150 * 1024 && !coop_pref) ? 1 : 0;
         if (wantr && need <= 160 * 1024) {
           e->resident = true;
           e->res_lds = need;
-          if (n + M <= 192 && M > 0 && !(getenv("MIOSQP_RES_W") && atoi(getenv("MIOSQP_RES_W")) == 0)) {
+          if (res_w) {
             // the explicit KKT inverse for the register-resident loop (res_admm_w, kernels_resident.inc)
             d.ldw = (n + M + 7) & ~7;
             double *Wd = nullptr;
@@ -858,7 +863,9 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     return MIOSQP_EARG;
   }
   const int n = e->n, M = e->M, p = e->d.n_int;
-  const size_t lds = tree_lds_doubles(n, M) * sizeof(double);
+  // (the tree kernels decide the same way on the device: explicit inverse there and n + M small enough -> no product
+  //  form in LDS; an engine without W yet gets it below when n + M <= 64, which only shrinks what the kernel uses)
+  const size_t lds = tree_lds_doubles(n, M, e->d.W != nullptr && n + M <= RES_W_MAX) * sizeof(double);
   if (!e->fold || lds > 160 * 1024 || p < 1) {  // whatever form single nodes use: the product-form rows must exist and fit
     g_err = "solve_tree: only for problems whose product-form factor, iterates and leaf list fit 160 KB of LDS";
     return MIOSQP_EUNSUPPORTED;

@@ -16,9 +16,16 @@ from miosqp_amd import bnb
 
 
 class HostedSearch(object):
-    def __init__(self, model, capacity=None):
-        self.model, self.work = model, model.work
-        w = self.work
+    def __init__(self, model, capacity=None, owned=False):
+        """owned: this object is kept BY the model's workspace (bnb.MIOSQP._solve_hosted): it then refers back through
+        weak proxies, so that dropping the model frees the engine at once (a reference cycle would keep the device pool and
+        the stream / pinned-buffer bundle until the cyclic collector runs -- the next setup then pays for new ones)."""
+        if owned:
+            import weakref
+            self.model, self.work = weakref.proxy(model), weakref.proxy(model.work)
+        else:
+            self.model, self.work = model, model.work
+        w = model.work
         self.eng = w.solver
         if not hasattr(self.eng, "search_create"):
             raise RuntimeError("the engine has no hosted search (miosqp_qp_search_*)")

@@ -788,10 +788,12 @@ def test_cooperative_solver_equals_two_kernel_form(oracle_mod, n, m, p, seed):
         x, y = ra.x, ra.y
 
 
-@pytest.mark.parametrize("n,m,p", [(20, 39, 4), (20, 40, 4), (21, 38, 6), (300, 600, 124), (300, 600, 125), (600, 1100, 348),
+@pytest.mark.parametrize("n,m,p", [(20, 39, 4), (20, 40, 4), (21, 38, 6), (40, 80, 8), (60, 120, 12), (60, 121, 12),
+                                    (300, 600, 124), (300, 600, 125), (600, 1100, 348),
                                     (600, 1100, 349), (700, 1000, 341), (1000, 40, 8), (30, 900, 20)])
 def test_engine_form_boundaries(oracle_mod, n, m, p):
-    """Sizes on the edges of the automatic choice (n+M = 64: LDS-resident below, cooperative from there;
+    """Sizes on the edges of the automatic choice (n+M <= 192: one workgroup -- its loop on the explicit inverse in
+    registers, in 2 or 4 parts per row: 64 / 128 / 192 are edges of that layout; cooperative from 193;
     1024 / 1025: two register layouts; 2041…2048: the last full grid of 256 workgroups; 2049: back to the
     two-kernel form) and lopsided shapes (few constraints, few variables, odd widths)."""
     from miosqp_amd import qp
@@ -802,7 +804,7 @@ def test_engine_form_boundaries(oracle_mod, n, m, p):
     g.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
     fs = g.factor_stats()
-    assert fs["coop"] == (64 <= N <= 2048) and fs["resident"] == (N < 64), (N, fs)
+    assert fs["coop"] == (192 < N <= 2048) and fs["resident"] == (N <= 192), (N, fs)
     rng = np.random.RandomState(N)
     x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(A.shape[0])
     for k in (1, 27):
