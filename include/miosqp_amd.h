@@ -63,13 +63,14 @@ typedef struct miosqp_qp_settings {
   int32_t max_batch;         /* capacity of miosqp_qp_solve_batch (>= 1) */
   int32_t fold;              /* -1 auto, 0 factor form L (4 kernels/iteration), 1 product form L^-1
                                 (2 kernels/iteration; auto picks it for panels denser than 30 %) */
-  int32_t resident;          /* -1 auto, 0 off, 1 on: whole solve in ONE LDS-resident workgroup when the
-                                product-form factor and all iterates fit in 160 KB of LDS */
+  int32_t resident;          /* -1 auto, 0 off, 1 on: whole solve in ONE workgroup: iterates in LDS; the factor as the
+                                explicit KKT inverse in the workgroup's registers (n+M <= 192, the automatic
+                                choice there) or in product form in LDS (when that fits 160 KB) */
   int32_t setup_on_device;   /* -1 auto (n >= 1024), 0 host, 1 device: dense LDL^T of the reduced Hessian and
                                 the inverse of its triangular factor computed on the GPU at setup */
   int32_t coop;              /* -1 auto, 0 off, 1 on: cooperative register-resident solver -- the explicit KKT
                                 inverse (n+M)^2 spread over the register files of up to one workgroup per
-                                CU, ONE exchange per iteration (n+M <= 2048; auto from n+M = 64 on) */
+                                CU, ONE exchange per iteration (n+M <= 2048; auto from n+M = 193 on) */
   int32_t reserved[2];
 } miosqp_qp_settings;
 
