@@ -1551,3 +1551,42 @@ print("RESULT " + json.dumps(out))
             np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-7)
         else:
             assert not np.isfinite(b["upper"])
+
+
+def test_resident_register_loop_sweep(oracle_mod):
+    """The one-workgroup solver with its loop on the explicit inverse in registers (res_admm_w) against the oracle on a
+    sweep of shapes that move through its layouts: n+M from 9 to 192 (2 or 4 parts per row, 1-6 chunks of 16 columns per
+    lane, widths that are and are not multiples of 16, more variables than constraints and the reverse): same status and
+    iteration count, x and y within the solution tolerance; and the product-form sweeps (MIOSQP_RES_W=0 is read per
+    setup) give the same on the same inputs."""
+    from miosqp_amd import qp
+    shapes = [(5, 2, 2), (8, 7, 1), (12, 3, 1), (15, 30, 3), (16, 31, 1), (17, 30, 1), (30, 30, 4), (20, 90, 2), (60, 4, 0),
+              (40, 70, 18), (64, 63, 1), (64, 64, 0), (33, 100, 27), (90, 80, 22), (100, 60, 32), (6, 180, 6)]
+    for k, (n, m, p) in enumerate(shapes):
+        pr = problems.random_miqp(n, m, max(p, 1), seed=200 + k)
+        A, l, u = problems.extended(pr)
+        N = n + A.shape[0]
+        assert N <= 192
+        o = oracle_mod.OSQP()
+        o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+        rng = np.random.RandomState(k)
+        x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(A.shape[0])
+        o.warm_start(x=x0, y=y0)
+        ro = o.solve()
+        for w in ("1", "0"):
+            os.environ["MIOSQP_RES_W"] = w
+            try:
+                g = qp.OSQP()
+                g.setup(pr["P"], pr["q"], A, l, u, resident=1, coop=0, **problems.QP_SETTINGS)
+            finally:
+                os.environ.pop("MIOSQP_RES_W", None)
+            if not g.factor_stats()["resident"]:
+                assert w == "0", (n, m, p)  # (the product form of this shape does not fit the LDS)
+                g.close()
+                continue
+            g.warm_start(x=x0, y=y0)
+            rg = g.solve()
+            assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), (n, m, p, w)
+            if ro.info.status_val == 1:
+                assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL, (n, m, p, w)
+            g.close()
