@@ -181,6 +181,7 @@ class StreamSearch(object):
         """(Re)starts on the model's current root: call after MIOSQP.update_vectors.  seed_root=False starts with
         no leaf at all (the sharded search hands this rank its share through add_leaf)."""
         w = self.work
+        self._inst0 = self.nodes  # nodes solved before this instance (run()'s cap counts from here)
         self.eng.pool_reset()
         for k in range(self.capacity):
             self._decided[k] = False
@@ -391,7 +392,7 @@ class StreamSearch(object):
         w = self.work
         cap = w.settings['max_iter_bb'] if max_nodes is None else max_nodes
         alive = 1
-        while alive > 0 and self.nodes + 1 < cap:
+        while alive > 0 and self.nodes - self._inst0 + 1 < cap:  # (the cap counts the nodes of THIS instance)
             alive = self.step(chunks)
         w.osqp_iter_avg = w.osqp_iter / float(max(1, w.iter_num))
         w.get_return_status(finished=(alive == 0))
@@ -443,6 +444,7 @@ class NativeStreamSearch(object):
 
     def begin_instance(self, seed_root=True):
         w = self.work
+        self._inst0 = self.nodes  # nodes solved before this instance (run()'s cap counts from here)
         self.eng.stream_begin()
         self._open, self.in_flight, self._free = 0, 0, self.capacity
         if seed_root:
@@ -480,8 +482,8 @@ class NativeStreamSearch(object):
         w = self.work
         cap = w.settings['max_iter_bb'] if max_nodes is None else max_nodes
         alive = 1
-        while alive > 0 and self.nodes + 1 < cap:
-            alive = self.step(chunks, rounds=64, max_nodes=cap)
+        while alive > 0 and self.nodes - self._inst0 + 1 < cap:  # (the cap counts the nodes of THIS instance)
+            alive = self.step(chunks, rounds=64, max_nodes=self._inst0 + cap)
         w.osqp_iter_avg = w.osqp_iter / float(max(1, w.iter_num))
         w.get_return_status(finished=(alive == 0))
         w.get_return_solution()

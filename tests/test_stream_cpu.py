@@ -100,3 +100,28 @@ def test_several_pools_share_one_tree():
         assert r1.status == r0.status
         assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
         seq.update_vectors(q=pr["q"])
+
+
+def test_the_node_cap_of_run_counts_the_nodes_of_the_current_instance():
+    """A driver that lives across a sequence of MIQPs (update_vectors + begin_instance) applies max_iter_bb to every
+    instance afresh: with the cap between one tree's size and the sequence's total, every instance still closes."""
+    pr = problems.random_miqp(20, 100, 10, seed=3)
+    seq, mdl = _models(pr, max_iter_bb=10 ** 6)
+    probe = stream.StreamSearch(mdl, columns=8, capacity=512)
+    probe.run()
+    per_tree = probe.nodes
+    assert per_tree >= 3
+    seq2, mdl2 = _models(pr, max_iter_bb=2 * per_tree + 8)
+    s = stream.StreamSearch(mdl2, columns=8, capacity=512)
+    rng = np.random.RandomState(5)
+    total = 0
+    for inst in range(5):
+        r0, r1 = seq2.solve(), s.run()
+        assert r1.status == r0.status == bnb.MI_SOLVED, inst
+        assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+        total = s.nodes
+        q2 = rng.randn(20)
+        for x in (seq2, mdl2):
+            x.update_vectors(q=q2)
+        s.begin_instance()
+    assert total > 2 * per_tree + 8  # (the sequence as a whole went past the cap: only a per-instance count lets it)
