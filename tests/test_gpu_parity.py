@@ -1590,3 +1590,34 @@ def test_resident_register_loop_sweep(oracle_mod):
             if ro.info.status_val == 1:
                 assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL, (n, m, p, w)
             g.close()
+
+
+def test_whole_tree_kernels_random_sweep(oracle_mod):
+    """MIOSQP.solve on the HIP engine (whole tree in one launch: k_tree_w for n+M <= 64, k_tree above) against the same
+    search on the CPU oracle over random small MIQPs -- odd and even n (compressed rows are padded to even length with
+    a zero that repeats a column index: a dense copy must not let it overwrite an entry), few and many constraints, both
+    exploration rules, update_vectors re-solves: status, node count, optimum, integer part of x."""
+    from miosqp_amd import bnb
+    rng = np.random.RandomState(2024)
+    for k in range(90):
+        n = int(rng.randint(4, 61))
+        m = int(rng.randint(1, 91))
+        p = int(rng.randint(1, min(n, 12) + 1))
+        rule = int(rng.randint(0, 2))
+        pr = problems.random_miqp(n, m, p, seed=1000 + k)
+        st = dict(problems.BNB_SETTINGS, tree_explor_rule=rule)
+        a, b = bnb.MIOSQP(), bnb.MIOSQP(backend=oracle_mod)
+        for mdl in (a, b):
+            mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+                      dict(problems.QP_SETTINGS))
+        for step in range(2):
+            ra, rb = a.solve(), b.solve()
+            assert not getattr(a.work, "_no_tree", False), (n, m, p)
+            assert ra.status == rb.status and a.work.iter_num == b.work.iter_num, (k, n, m, p, rule, step)
+            if np.isfinite(rb.upper_glob):
+                assert abs(ra.upper_glob - rb.upper_glob) <= 1e-6 * max(1.0, abs(rb.upper_glob)), (k, n, m, p, rule, step)
+                np.testing.assert_array_equal(np.round(ra.x[pr["i_idx"]]), np.round(rb.x[pr["i_idx"]]))
+            q2 = rng.randn(n)
+            a.update_vectors(q=q2)
+            b.update_vectors(q=q2)
+        a.work.solver.close()
