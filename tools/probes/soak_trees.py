@@ -23,7 +23,7 @@ for k in range(count):
     p = int(rng.randint(1, min(n, 12) + 1))
     rule = int(rng.randint(0, 2))
     pr = problems.random_miqp(n, m, p, seed=1000 + k)
-    st = dict(problems.BNB_SETTINGS, tree_explor_rule=rule)
+    st = dict(problems.BNB_SETTINGS, tree_explor_rule=rule, **({"device_tree": False} if os.environ.get("SOAK_HOSTED") else {}))
     a, b = bnb.MIOSQP(), bnb.MIOSQP(backend=oracle)
     for mdl in (a, b):
         mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
