@@ -70,3 +70,24 @@ def test_sharded_hosted_search(world, every, deal_to):
         np.testing.assert_array_equal(o["x"][pr["i_idx"]], r.x[pr["i_idx"]])
     if deal_to is not None:
         assert out[deal_to]["moved"] >= 1
+
+
+def test_dropping_the_model_frees_the_engine_at_once():
+    """The hosted search object is kept by the model's workspace and refers back weakly: no reference cycle, so the engine
+    (device pool, stream and pinned-buffer bundle on the GPU) goes when the model goes -- not when the cyclic collector
+    happens to run (the next setup would pay for a new bundle)."""
+    import gc
+    import weakref
+    pr = problems.random_miqp(20, 40, 10, seed=1)
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        m = _model(pr)
+        m.solve()
+        assert getattr(m.work, "_hosted", None) is not None
+        refs = [weakref.ref(m), weakref.ref(m.work), weakref.ref(m.work.solver), weakref.ref(m.work._hosted)]
+        m = None
+        assert all(r() is None for r in refs)
+    finally:
+        if was:
+            gc.enable()
