@@ -985,7 +985,22 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
       memcpy(e->h_out, x_inc0, sizeof(double) * n);
       HIPCHK(hipMemcpyAsync(e->ta.inc_x, e->h_out, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
     }
-    hipLaunchKernelGGL(k_tree, dim3(1), dim3(RES_THREADS), lds, e->stream, e->d, ta);
+    static unsigned long long *ktree_prof = nullptr;  // debug (MIOSQP_TREE_PROF=1), as for the one-wavefront kernel
+    static const bool ktree_prof_on = getenv("MIOSQP_TREE_PROF") != nullptr;
+    if (ktree_prof_on && !ktree_prof) {
+      HIPCHK(hipMalloc((void **)&ktree_prof, 128));
+      HIPCHK(hipMemset(ktree_prof, 0, 128));
+    }
+    Dev dk = e->d;
+    if (ktree_prof_on) dk.prof = ktree_prof;
+    hipLaunchKernelGGL(k_tree, dim3(1), dim3(RES_THREADS), lds, e->stream, dk, ta);
+    if (ktree_prof_on) {
+      unsigned long long h[16];
+      HIPCHK(hipMemcpyAsync(h, ktree_prof, sizeof h, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      fprintf(stderr, "[tree prof] k_tree cumulative us: choose+prologue %.1f  relaxation %.1f  epilogue %.1f  branch+children %.1f\n",
+              h[8] / 100.0, h[9] / 100.0, h[10] / 100.0, h[11] / 100.0);
+    }
     HIPCHK(hipMemcpyAsync(e->h_out, e->ta.inc_x, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
     static_assert(sizeof(TreeOut) <= sizeof(Ctrl), "TreeOut travels through the pinned control block");
     HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ta.out, sizeof(TreeOut), hipMemcpyDeviceToHost, e->stream));
