@@ -495,7 +495,15 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       e->tpr_fc = pick_tpr((double)n);
       {
         const bool res_w = n + M <= RES_W_MAX && M > 0 && !(getenv("MIOSQP_RES_W") && atoi(getenv("MIOSQP_RES_W")) == 0);
-        const size_t need = resident_lds_doubles(n, M, res_w) * sizeof(double);
+        size_t need = resident_lds_doubles(n, M, res_w) * sizeof(double);
+        e->sp_nnzA = f.panel_by_con.idx.size();
+        e->sp_nnzP = f.Pbar.idx.size();
+        const bool sp_on = res_w && !(getenv("MIOSQP_RES_SP") && atoi(getenv("MIOSQP_RES_SP")) == 0);
+        const size_t sp_bytes = res_sp_doubles(e->sp_nnzA, e->sp_nnzP, n, M) * sizeof(double);
+        if (sp_on && need + sp_bytes <= 150 * 1024) {  // room for the sparse rows of the termination test in LDS
+          e->res_sp_off = (int)(need / sizeof(double));
+          need += sp_bytes;
+        }
         int wantr = s->resident;
         if (wantr < 0) wantr = (need <= 150 * 1024 && !coop_pref) ? 1 : 0;
         if (wantr && need <= 160 * 1024) {
@@ -865,7 +873,17 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
   const int n = e->n, M = e->M, p = e->d.n_int;
   // (the tree kernels decide the same way on the device: explicit inverse there and n + M small enough -> no product
   //  form in LDS; an engine without W yet gets it below when n + M <= 64, which only shrinks what the kernel uses)
-  const size_t lds = tree_lds_doubles(n, M, e->d.W != nullptr && n + M <= RES_W_MAX) * sizeof(double);
+  const bool tree_w = e->d.W != nullptr && n + M <= RES_W_MAX;
+  size_t lds = tree_lds_doubles(n, M, tree_w) * sizeof(double);
+  int tree_sp_off = -1;
+  {
+    const size_t sp_bytes = res_sp_doubles(e->sp_nnzA, e->sp_nnzP, n, M) * sizeof(double);
+    if (tree_w && e->sp_nnzA > 0 && lds + sp_bytes <= 160 * 1024 &&
+        !(getenv("MIOSQP_RES_SP") && atoi(getenv("MIOSQP_RES_SP")) == 0)) {
+      tree_sp_off = (int)(lds / sizeof(double));
+      lds += sp_bytes;
+    }
+  }
   if (!e->fold || lds > 160 * 1024 || p < 1) {  // whatever form single nodes use: the product-form rows must exist and fit
     g_err = "solve_tree: only for problems whose product-form factor, iterates and leaf list fit 160 KB of LDS";
     return MIOSQP_EUNSUPPORTED;
@@ -921,6 +939,7 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
   }
   ta.upper0 = have_inc ? upper0 : 1.0 / 0.0;
   ta.done = nullptr;
+  ta.sp_off = tree_sp_off;
   const TreeOut *o = nullptr;
   const double *x_found = nullptr;
   float ms = 0;
