@@ -22,9 +22,10 @@ def rel(a, b):
 
 
 for k in range(count):
-    n = int(rng.randint(3, 260))
-    m = int(rng.randint(1, 520))
-    p = int(rng.randint(1, min(n, 40) + 1))
+    small = os.environ.get("SOAK_SMALL")  # SOAK_SMALL=1: shapes of the one-workgroup kernels (n+M <= 192)
+    n = int(rng.randint(3, 70 if small else 260))
+    m = int(rng.randint(1, 100 if small else 520))
+    p = int(rng.randint(1, min(n, 20 if small else 40) + 1))
     pr = problems.random_miqp(n, m, p, seed=5000 + k, density=float(rng.choice([0.05, 0.3, 0.7])))
     A, l, u = problems.extended(pr)
     g, o = qp.OSQP(), oracle.OSQP()
