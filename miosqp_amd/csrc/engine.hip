@@ -786,11 +786,16 @@ int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *
     return MIOSQP_EARG;
   }
   ENTER(e);
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (e->M > 0) {  // (on the engine's stream: see miosqp_qp_pool_write_node)
-    HIPCHK(hipMemcpyAsync(e->d.root_l, l_root, sizeof(double) * e->M, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d.root_u, u_root, sizeof(double) * e->M, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->M > 0) {
+    // through the pinned staging block, on the engine's stream, no wait: whatever reads the root bounds is queued
+    // behind these copies (two blocking copies from pageable memory and two stream synchronisations were 40 us of an
+    // MPC step's 90)
+    if (int rcw = stage_wait(e, 0)) return rcw;
+    memcpy(e->h_in, l_root, sizeof(double) * e->M);
+    memcpy(e->h_in + e->M, u_root, sizeof(double) * e->M);
+    HIPCHK(hipMemcpyAsync(e->d.root_l, e->h_in, sizeof(double) * e->M, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d.root_u, e->h_in + e->M, sizeof(double) * e->M, hipMemcpyHostToDevice, e->stream));
+    if (int rcm = stage_mark(e, 0)) return rcm;
   }
   if (e->x_stream && (e->d.eps_int != eps_int_feas || e->d.eps_lin != eps_lin)) drop_stream_graph(e);  // captured by value
   e->d.eps_int = eps_int_feas;

@@ -1621,3 +1621,34 @@ def test_whole_tree_kernels_random_sweep(oracle_mod):
             a.update_vectors(q=q2)
             b.update_vectors(q=q2)
         a.work.solver.close()
+
+
+def test_native_stream_driver_applies_the_node_cap_per_instance():
+    """A compiled streaming driver kept across a sequence of MIQPs: max_iter_bb counts the nodes of the current instance
+    (it used to count the driver's lifetime: the first instance after the cap was reached returned at once)."""
+    from miosqp_amd import bnb, stream
+    pr = problems.random_miqp(30, 60, 12, seed=5)
+    probe = bnb.MIOSQP()
+    probe.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 6), dict(problems.QP_SETTINGS, max_batch=64))
+    s0 = stream.NativeStreamSearch(probe, columns=64, capacity=2048)
+    s0.run()
+    per_tree = s0.nodes
+    assert per_tree >= 3
+    probe.work.solver.close()
+    cap = 3 * per_tree + 16
+    seq, mdl = bnb.MIOSQP(), bnb.MIOSQP()
+    for m in (seq, mdl):
+        m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS, max_iter_bb=cap), dict(problems.QP_SETTINGS, max_batch=64))
+    s = stream.NativeStreamSearch(mdl, columns=64, capacity=2048)
+    rng = np.random.RandomState(6)
+    for inst in range(6):
+        r0, r1 = seq.solve(), s.run()
+        assert r1.status == r0.status == bnb.MI_SOLVED, inst
+        assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+        q2 = rng.randn(30)
+        seq.update_vectors(q=q2)
+        mdl.update_vectors(q=q2)
+        s.begin_instance()
+    assert s.nodes > cap
