@@ -186,7 +186,9 @@ typedef struct miosqp_search_info {
   int64_t osqp_iter;    /* ADMM iterations over them */
   int32_t open_leaves;  /* leaves still open (0: the tree is closed) */
   int32_t free_slots;
-  int32_t improved;     /* 1: the incumbent improved in this call */
+  int32_t improved;     /* the incumbent improved in this call: 1 = last by an integer-feasible node, 2 = last by the
+                           rounding heuristic (its value is the device's sum: recompute on the host and hand it back
+                           through miosqp_qp_search_set_incumbent(e, value, NULL) for workspace.py:321-327's number) */
   int32_t reserved;
   double upper_glob, lower_glob;
   double device_time;   /* seconds inside the ADMM loops of these nodes (device events) */
@@ -202,11 +204,14 @@ int miosqp_qp_search_add_leaf(miosqp_qp_engine *e, const double *l_int, const do
 /* removes the shallowest open leaf and returns it with explicit vectors; 1 when there is none */
 int miosqp_qp_search_take_leaf(miosqp_qp_engine *e, double *l_int, double *u_int, double *x0, double *y0,
                                int32_t *depth, double *lower);
-/* adopts an incumbent from outside when it is better (MIOSQP.set_x0, another rank) and prunes against it */
+/* adopts an incumbent from outside when it is better (MIOSQP.set_x0, another rank) and prunes against it;
+ * x == NULL: only the VALUE of the incumbent the search already holds is replaced (no comparison, no pruning) */
 int miosqp_qp_search_set_incumbent(miosqp_qp_engine *e, double upper, const double *x);
 /* *upper >= 1.7e308: none yet (x untouched) */
 int miosqp_qp_search_get_incumbent(miosqp_qp_engine *e, double *upper, double *x);
-/* solves nodes until the list is empty, max_nodes are done or budget_s seconds have passed (<= 0: no time limit) */
+/* solves nodes until the list is empty, max_nodes are done or budget_s seconds have passed (<= 0: no time limit).
+ * The slot store grows by itself (the capacity of search_create is a starting size); MIOSQP_EFULL only when the
+ * device has no memory left for it -- *info is filled with what was done up to then in that case too. */
 int miosqp_qp_search_run(miosqp_qp_engine *e, int32_t tree_explor_rule, int64_t max_nodes, double budget_s,
                          miosqp_search_info *info);
 

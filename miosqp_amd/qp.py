@@ -197,6 +197,8 @@ class OSQP(object):
         have = x_inc0 is not None and np.isfinite(upper0)
         xin = _f64(x_inc0, self.n, "x_inc0") if have else None
         x, info = np.empty(self.n), _lib.TreeInfo()
+        # the launch counts nodes in 32 bits; the reference accepts any number here (also inf): clamp
+        max_iter_bb = 2 ** 31 - 1 if not np.isfinite(max_iter_bb) else int(min(int(max_iter_bb), 2 ** 31 - 1))
         rc = self._lib.miosqp_qp_solve_tree(self._h, _lib.as_d(l), _lib.as_d(u), _lib.as_d(x0), _lib.as_d(y0),
                                             float(upper0) if have else float("inf"), _lib.as_d(xin) if have else None,
                                             int(tree_explor_rule), int(max_iter_bb), _lib.as_d(x), C.byref(info))
@@ -233,7 +235,10 @@ class OSQP(object):
         return None if rc == 1 else (l, u, x, y, depth.value, lower.value)
 
     def search_set_incumbent(self, upper, x):
-        _check(self._lib.miosqp_qp_search_set_incumbent(self._h, float(upper), _lib.as_d(_f64(x, self.n, "x"))),
+        """x None: only the VALUE of the incumbent the search already holds is replaced (a rounding-heuristic value
+        recomputed on the host, see SearchInfo.improved == 2)."""
+        _check(self._lib.miosqp_qp_search_set_incumbent(self._h, float(upper),
+                                                        None if x is None else _lib.as_d(_f64(x, self.n, "x"))),
                "search_set_incumbent")
 
     def search_get_incumbent(self):
@@ -243,9 +248,14 @@ class OSQP(object):
         return (upper.value, x) if upper.value < 1.7e308 else (float("inf"), None)
 
     def search_run(self, tree_explor_rule, max_nodes, budget_s=0.0):
+        """Returns the info record; `info.full` is set when the slot store could not grow any further (the device is
+        out of memory): the counters of the nodes done in this call are valid, the caller decides what to do."""
         info = self._search_info
-        _check(self._lib.miosqp_qp_search_run(self._h, int(tree_explor_rule), int(max_nodes), float(budget_s),
-                                              C.byref(info)), "search_run")
+        max_nodes = 2 ** 62 if not np.isfinite(max_nodes) else int(min(int(max_nodes), 2 ** 62))
+        rc = self._lib.miosqp_qp_search_run(self._h, int(tree_explor_rule), max_nodes, float(budget_s), C.byref(info))
+        info.full = rc == -6
+        if not info.full:
+            _check(rc, "search_run")
         return info
 
     # -- the host side of the streaming search, compiled (miosqp_qp_stream_*) ---------------------------

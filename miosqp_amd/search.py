@@ -6,8 +6,10 @@ to a 800 us relaxation on config 2.  Here the open leaves are device slots, the 
 a node's outcome is a 96-byte record and the loop itself is compiled code; Python sees the search between calls
 (after a node, a batch of nodes or a time budget): for the incumbent exchange of the sharded search, for handing
 leaves to other ranks, for an observer.  Same list semantics and decisions as bnb.Workspace (creation order, first
-maximum, the prune traversal of workspace.py:278-280); the value of an incumbent found by the rounding heuristic is
-the device's (bnb recomputes it with numpy: ~1e-12 relative apart).
+maximum, the prune traversal of workspace.py:278-280).  An incumbent found by the rounding heuristic carries the
+device's sum while the compiled loop runs; when the call returns its value is recomputed on the host as
+workspace.py:321-327 does and handed back (`search_set_incumbent(value, None)`), so results and later comparisons use
+the reference's number (the two agree to ~1e-12 relative).
 
 HostedSearch has the interface of stream.StreamSearch, so dist.ShardedStream shards either."""
 import numpy as np
@@ -60,6 +62,8 @@ class HostedSearch(object):
         """(Re)starts on the model's current root: call after MIOSQP.update_vectors."""
         w = self.work
         self.eng.search_reset()
+        # (the slot store grows on demand: ask what it holds now)
+        self.capacity = int(self.eng.search_run(w.settings['tree_explor_rule'], 0).free_slots)
         self._open, self._free = 0, self.capacity
         if seed_root:
             root = w.leaves[0] if w.leaves else w._make_root()
@@ -106,6 +110,16 @@ class HostedSearch(object):
         if info.improved:
             w.upper_glob, x = self.eng.search_get_incumbent()
             w.x = x
+            if info.improved == 2:
+                # found by the rounding heuristic: its value is recomputed exactly as workspace.py:321-327 does (the
+                # device sums in another order, ~1e-12 relative apart) and handed back, so that what the caller sees
+                # and every later comparison use the reference's number
+                w.upper_glob = float(w.data.compute_obj_val(x))
+                self.eng.search_set_incumbent(w.upper_glob, None)
+        if getattr(info, "full", False):
+            # the device has no memory left for more open leaves: the counters above are consistent, say what happened
+            raise MemoryError("hosted search: the leaf store cannot grow any further (%d open leaves, %d nodes done)"
+                              % (self._open, w.iter_num))
         return self._open
 
     def run(self, max_nodes=None):

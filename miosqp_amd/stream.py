@@ -493,7 +493,7 @@ class NativeStreamSearch(object):
 class MultiPoolSearch(object):
     """Several streaming pools on ONE GPU, one tree.  `pools` engines of the same MIQP (each its own stream, batch
     and leaf pool; the factor is set up once per engine) are driven by `pools` host threads and share the tree like
-    ranks do (dist.ShardedStream over dist.ThreadComm: replicated ramp-up, deal, incumbent + dry-pool feed every
+    ranks do (dist.ShardedStream over poolcomm.PoolComm: replicated ramp-up, deal, incumbent + dry-pool feed every
     `exchange_every` chunks).  A chunk of the streaming batch has a serial part -- termination test, harvest, refill:
     twenty small kernels, 190 us of 970 at config 3 -- during which the chip is nearly idle; with two pools the
     sweeps of one fill those gaps of the other: 6.3 -> 8.7 M node-iterations/s at 2 x 256 columns on MI355X.
@@ -506,13 +506,14 @@ class MultiPoolSearch(object):
         """driver: "python" -- every pool's rounds in StreamSearch (one interpreter, `pools` threads taking turns on its
         lock between two chunks); "native" -- in NativeStreamSearch (the C++ library runs `exchange_every` rounds per
         call without the lock; the threads only meet the interpreter for the exchange)."""
-        from miosqp_amd import dist
+        from miosqp_amd import dist, poolcomm
         if driver not in ("python", "native"):
             raise ValueError("driver: 'python' or 'native'")
         self.driver = driver
         self.pools = int(pools)
         self.models = [make_model() for _ in range(self.pools)]
-        self.world = dist.ThreadWorld(self.pools)
+        self.world = poolcomm.PoolWorld(self.pools)
+        self._poolcomm = poolcomm
         self.columns, self.exchange_every, self.capacity = columns, exchange_every, capacity
         self.sh = [None] * self.pools
         self._dist = dist
@@ -526,10 +527,7 @@ class MultiPoolSearch(object):
                 out[k] = fn(k)
             except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
                 err.append(e)
-                try:
-                    self.world.bar.abort()
-                except Exception:
-                    pass
+                self.world.fail(e)  # peers waiting in a barrier or an exchange raise at once
 
         ths = [threading.Thread(target=body, args=(k,)) for k in range(self.pools)]
         for t in ths:
@@ -542,7 +540,7 @@ class MultiPoolSearch(object):
 
     def _shard(self, k):
         if self.sh[k] is None:
-            comm = self._dist.ThreadComm(self.world, k)
+            comm = self._poolcomm.PoolComm(self.world, k)
             if self.driver == "native":
                 ns = NativeStreamSearch(self.models[k], columns=self.columns, capacity=self.capacity,
                                         rounds=self.exchange_every)

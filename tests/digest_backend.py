@@ -199,6 +199,10 @@ class OSQP(oracle.OSQP):
 
     def search_set_incumbent(self, upper, x):
         sc = self._sc
+        if x is None:  # only the value of the incumbent held (a heuristic value recomputed by the caller)
+            assert sc["inc"] is not None
+            sc["upper"] = float(upper)
+            return
         if upper < sc["upper"]:
             sc["upper"], sc["inc"] = float(upper), np.array(x, dtype=float)
             self._search_prune()
@@ -239,7 +243,7 @@ class OSQP(oracle.OSQP):
             if dg.heur_feasible and dg.heur_obj < sc["upper"]:
                 xr = r.x.copy()
                 xr[self._ii] = np.round(xr[self._ii])
-                sc["upper"], sc["inc"], improved = float(dg.heur_obj), xr, 1
+                sc["upper"], sc["inc"], improved = float(dg.heur_obj), xr, 2
                 self._search_prune()
             xv = r.x[self._ii[dg.nextvar]]
             for side in (0, 1):

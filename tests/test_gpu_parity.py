@@ -588,6 +588,38 @@ def test_config5_full_size_properties():
         assert np.all(xi2 >= L2[i][m:] - 0) and np.all(xi2 <= U2[i][m:] + 0)
 
 
+def test_config5_against_the_oracle_fixture():
+    """BASELINE config 5 at full size against the CPU oracle: tests/golden/cfg5_root.npz holds what oracle/qp_oracle.c
+    returned (build container, tests/golden/make_cfg5_fixture.py) for the root and its two children in the reference's
+    call order (node.py:102-143): status, iteration count, x after the integer clamp, y, lower bound."""
+    from miosqp_amd import qp
+    from golden_cases import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "cfg5_root.npz"), allow_pickle=False)
+    pr = problems.random_miqp(**problems.CONFIGS["cfg5"], seed=0)
+    assert problems.instance_digest(pr) == str(z["digest"]), "scipy's sampling changed: regenerate the fixture"
+    A, l, u = problems.extended(pr)
+    n, M, m = 5000, A.shape[0], 10000
+    g = qp.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    g.set_integer_rows(pr["i_idx"], m)
+    k = int(z["branch_k"])
+    lo, up = [l.copy(), l.copy()], [u.copy(), u.copy()]
+    up[0][m + k] = float(z["branch_floor"])
+    lo[1][m + k] = float(z["branch_ceil"])
+    nodes = [("root", l, u, np.zeros(n), np.zeros(M)),
+             ("child0", lo[0], up[0], z["root_x"], z["root_y"]), ("child1", lo[1], up[1], z["root_x"], z["root_y"])]
+    for name, nl, nu, x0, y0 in nodes:
+        r = g.solve_node(nl, nu, x0, y0)
+        assert (r.status_val, r.iter) == (int(z[name + "_status"]), int(z[name + "_iter"])), name
+        assert rel(r.x, z[name + "_x"]) <= SOL_TOL and rel(r.y, z[name + "_y"]) <= SOL_TOL, name
+        want = float(z[name + "_lower"])
+        assert abs(r.lower - want) <= 1e-9 * max(1.0, abs(want)), name
+    # the child pair is the one the GPU's own root solution would branch on as well
+    xi = g.solve_node(l, u, np.zeros(n), np.zeros(M)).x[pr["i_idx"]]
+    assert int(np.argmax(np.abs(xi - np.round(xi)))) == k
+    g.close()
+
+
 def test_setup_rejects_bad_input():
     import scipy.sparse as spa
     from miosqp_amd import qp
@@ -1032,12 +1064,15 @@ def test_single_rank_torchrun_goes_through_rccl(tmp_path):
     assert b["n_gpus"] == 1 and b["roofline"]["kernel"] == a["roofline"]["kernel"]
 
 
-def _stream_checker(pr, stride, seen, ref=None):
+def _stream_checker(pr, stride, seen, ref=None, oracle_mod=None, oracle_stride=0, oracle_seen=None):
     """observer for StreamSearch: every `stride`-th decided node is replayed through solve_node on a SECOND engine
     from what the pool holds for it (its integer-row bounds, its parent's solution as warm start) and must
     match the digest: status, iterations, bound, integrality count, branching variable, heuristic outcome, and
     the stored solution.  `ref`: that second engine when it exists already (a later MIQP of a sequence must go
-    through update(q=) like the engine under test: the cost scaling is fixed at setup)."""
+    through update(q=) like the engine under test: the cost scaling is fixed at setup).
+    With `oracle_mod`, every `oracle_stride`-th of those replays ALSO goes through the CPU oracle in the reference's
+    call order (node.py:102-143): status, iterations, x after the clamp, y and the bound of what the stream decided
+    are then checked against something that is not this engine."""
     from miosqp_amd import qp
     A, l, u = problems.extended(pr)
     m, p = pr["A"].shape[0], len(pr["i_idx"])
@@ -1046,7 +1081,12 @@ def _stream_checker(pr, stride, seen, ref=None):
         ref.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
         ref.set_integer_rows(pr["i_idx"], m)
         ref.set_root(l, u, 1e-3, 1e-3)
+    orc = None
+    if oracle_mod is not None and oracle_stride > 0:
+        orc = oracle_mod.OSQP()
+        orc.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
     count = [0]
+    ocount = [0]
 
     def obs(search, g):
         if int(g["status_val"]) == -100:
@@ -1066,6 +1106,22 @@ def _stream_checker(pr, stride, seen, ref=None):
         l2[m:], u2[m:] = nd.l, nd.u
         r = ref.solve_node(l2, u2, x0, y0)
         assert (int(g["status_val"]), int(g["iter"])) == (r.status_val, r.iter), s
+        if orc is not None:
+            ocount[0] += 1
+            if ocount[0] % oracle_stride == 0:
+                orc.update(l=l2, u=u2)
+                orc.warm_start(x=x0, y=y0)
+                ro = orc.solve()
+                assert (int(g["status_val"]), int(g["iter"])) == (ro.info.status_val, ro.info.iter), s
+                if ro.info.status_val in (1, -2):
+                    xo = ro.x.copy()
+                    ii = pr["i_idx"]
+                    xo[ii] = np.minimum(np.maximum(xo[ii], l2[m:]), u2[m:])
+                    lo = 0.5 * xo.dot(pr["P"].dot(xo)) + pr["q"].dot(xo)
+                    assert rel(nd.x, xo) <= SOL_TOL and rel(nd.y, ro.y) <= SOL_TOL
+                    assert abs(g["lower"] - lo) <= 1e-9 * max(1.0, abs(lo))
+                if oracle_seen is not None:
+                    oracle_seen.append(s)
         if r.status_val in (1, -2):
             assert abs(g["lower"] - r.lower) <= 1e-9 * max(1.0, abs(r.lower))
             assert rel(nd.x, r.x) <= SOL_TOL and rel(nd.y, r.y) <= SOL_TOL
@@ -1301,11 +1357,89 @@ def test_hosted_search_equals_the_python_loop(n, m, p, seed, rule):
         assert r3.upper_glob == r0.upper_glob - 1e-6 and cc.work.iter_num <= py.work.iter_num
 
 
+def _final_results(case, settings_extra, qp_extra, make_runner=None):
+    """Drives a golden case as make_bnb_traces.py drove the reference, without an observer (so that MIOSQP.solve() takes
+    its device-resident path), and returns per solve the final numbers.  make_runner(model) -> callable returning
+    Results replaces model.solve (the native stream driver)."""
+    from miosqp_amd import bnb
+    prob = case["prob"]
+    model = bnb.MIOSQP()
+    model.setup(prob["P"], prob["q"], prob["A"], np.copy(prob["l"]), np.copy(prob["u"]), prob["i_idx"], prob["i_l"],
+                prob["i_u"], dict(case["settings"], **settings_extra), dict(case["qp_settings"], **qp_extra))
+    run = model.solve if make_runner is None else make_runner(model)
+    out = []
+
+    def one():
+        res = run()
+        out.append(dict(x=np.array(res.x, dtype=float), upper_glob=res.upper_glob, status=res.status,
+                        osqp_iter=model.work.osqp_iter, iter_num=model.work.iter_num))
+
+    if case["x0"] is not None:
+        model.set_x0(np.copy(case["x0"]))
+    one()
+    for (q, l, u, x0u) in case["updates"]:
+        model.update_vectors(q=q, l=l, u=u)
+        if x0u is not None:
+            model.set_x0(np.copy(x0u))
+        one()
+    return out, model
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_hosted_search_follows_the_reference_traces(name):
+    """miosqp_qp_search_* -- the loop of solver.py:85-123 compiled into the host library, the bench headline's loop --
+    directly against what the REFERENCE recorded (tests/golden/bnb_*.npz, 13 cases: both exploration rules, node cap,
+    infeasible root, set_x0, update_vectors sequences): status, iter_num and osqp_iter identical (the loop visits the
+    same nodes in the same order and every relaxation takes the same iterations), x and upper_glob to tolerance."""
+    case = load_case(name)
+    got, model = _final_results(case, dict(device_tree=False), dict(resident=0))
+    hosted = getattr(model.work, "_hosted", None) is not None
+    assert hosted or case["prob"]["i_idx"].size == 0
+    assert len(got) == len(case["solves"])
+    for g, e in zip(got, case["solves"]):
+        assert g["status"] == e["status"]
+        assert (g["iter_num"], g["osqp_iter"]) == (e["iter_num"], e["osqp_iter"])
+        if e["status"] in ("Solved", "Max-iter feasible"):
+            assert rel(g["x"], e["x"]) <= SOL_TOL
+            assert abs(g["upper_glob"] - e["upper_glob"]) <= 1e-8 * max(1, abs(e["upper_glob"]))
+
+
+@pytest.mark.parametrize("name", [c for c in case_names() if "cap" not in c])
+def test_native_stream_driver_reaches_the_reference_optimum(name):
+    """The compiled streaming driver (miosqp_qp_stream_*: leaves in the device pool, many relaxations in flight) on the
+    reference's recorded cases: it explores in another order, so node counts differ by construction -- what must agree
+    with the reference is the final status and the optimum (value to 1e-8 relative; the integer part of x exactly).
+    (The node-capped case is left out: which incumbent exists when a cap strikes depends on the order.)"""
+    from miosqp_amd import stream
+    case = load_case(name)
+    if case["prob"]["i_idx"].size == 0:
+        pytest.skip("no integer variable")
+    holder = {}
+
+    def make_runner(model):
+        def run():
+            ns = holder.get("ns")
+            if ns is None:
+                ns = holder["ns"] = stream.NativeStreamSearch(model, columns=64, capacity=4096)
+            else:
+                ns.begin_instance()
+            return ns.run()
+        return run
+
+    got, model = _final_results(case, dict(max_iter_bb=10 ** 6), dict(max_batch=64), make_runner)
+    ii = case["prob"]["i_idx"]
+    for g, e in zip(got, case["solves"]):
+        assert g["status"] == e["status"], (g["status"], e["status"])
+        if e["status"] == "Solved":
+            assert abs(g["upper_glob"] - e["upper_glob"]) <= 1e-8 * max(1, abs(e["upper_glob"]))
+            np.testing.assert_array_equal(g["x"][ii], e["x"][ii])
+
+
 @pytest.mark.parametrize("form", [dict(coop=0, resident=0), dict(fold=0, coop=0, resident=0), dict(resident=1)])
 def test_hosted_search_on_every_engine_form(form):
     """The hosted loop drives whatever form the engine uses for single nodes (two-kernel product form with host-checked
     chunks, four-kernel factor form, LDS-resident workgroup): same nodes and iterations as the Python loop on that form;
-    a store with too few slots reports MIOSQP_EFULL instead of overwriting leaves."""
+    a store that starts with too few slots grows instead of overwriting leaves or giving up."""
     from miosqp_amd import bnb, search
     pr = problems.random_miqp(40, 60, 20, seed=7)
     st = dict(problems.BNB_SETTINGS, device_tree=False)
@@ -1318,13 +1452,15 @@ def test_hosted_search_on_every_engine_form(form):
     assert (r1.status, cc.work.iter_num, cc.work.osqp_iter) == (r0.status, py.work.iter_num, py.work.osqp_iter)
     assert abs(r1.upper_glob - r0.upper_glob) <= 1e-9 * max(1.0, abs(r0.upper_glob))
     np.testing.assert_array_equal(r1.x[pr["i_idx"]], r0.x[pr["i_idx"]])
-    # four slots: the root and its two children fit, the grandchildren do not
+    # four slots to start with: the store grows as the tree does (the reference's leaf list is unbounded) -- same search
     tiny = bnb.MIOSQP()
     tiny.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st, device_search=False), dict(qs))
     hs = search.HostedSearch(tiny, capacity=4)
+    r2 = hs.run()
+    assert (r2.status, tiny.work.iter_num, tiny.work.osqp_iter) == (r0.status, py.work.iter_num, py.work.osqp_iter)
+    assert abs(r2.upper_glob - r0.upper_glob) <= 1e-9 * max(1.0, abs(r0.upper_glob))
     if py.work.iter_num > 4:
-        with pytest.raises(RuntimeError, match="no free slot"):
-            hs.run()
+        assert hs._free + hs._open > 4  # it did grow
 
 
 def test_hosted_search_survives_a_called_off_cooperative_launch(monkeypatch):
@@ -1351,6 +1487,51 @@ def test_hosted_search_survives_a_called_off_cooperative_launch(monkeypatch):
     assert (r1.status, bad.work.iter_num, bad.work.osqp_iter) == (r0.status, ref.work.iter_num, ref.work.osqp_iter)
     assert r1.upper_glob == r0.upper_glob
     np.testing.assert_array_equal(r1.x, r0.x)
+
+
+def test_called_off_launch_leaves_slot_children_and_incumbent_alone(monkeypatch):
+    """A cooperative launch that is called off has touched no iterate: its epilogue must write the record and nothing
+    else.  The case that used to go wrong: a leaf adopted with explicit vectors (its slot IS its warm start) whose warm
+    start is integral and cheaper than the incumbent -- the epilogue of the called-off launch took it for an
+    integer-feasible solution and overwrote the incumbent's x on the device while the host (rightly) discarded the
+    record, so the x handed out at the end no longer belonged to upper_glob."""
+    import scipy.sparse.linalg as sla
+    from miosqp_amd import bnb, search
+    pr = problems.random_miqp(60, 120, 30, seed=11)
+    st = dict(problems.BNB_SETTINGS, device_tree=False)
+    ref = bnb.MIOSQP()
+    ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS, coop=0, resident=0))
+    r0 = ref.solve()
+    assert r0.status == bnb.MI_SOLVED
+    n, ii = 60, pr["i_idx"]
+    # an integral point far below the optimum (it ignores the constraints)
+    x0 = sla.spsolve((pr["P"] + 1e-6 * __import__("scipy.sparse").sparse.identity(n)).tocsc(), -pr["q"])
+    x0[ii] = np.clip(np.round(x0[ii]), 0.0, 1.0)
+    obj0 = 0.5 * x0.dot(pr["P"].dot(x0)) + pr["q"].dot(x0)
+    assert obj0 < r0.upper_glob - 1e-3
+    upper = 0.5 * (obj0 + r0.upper_glob)  # below every feasible point: nothing the search finds can replace it
+    marker = r0.x.copy()
+    cont = [i for i in range(n) if i not in set(ii.tolist())][0]
+    marker[cont] += 0.125
+    monkeypatch.setenv("MIOSQP_COOP_NAP", "12")
+    monkeypatch.setenv("MIOSQP_COOP_DBG", "64")  # workgroup 1 never shows up: the first launch is called off
+    bad = bnb.MIOSQP()
+    bad.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS, coop=1, resident=0))
+    monkeypatch.delenv("MIOSQP_COOP_DBG")
+    assert bad.work.solver.factor_stats()["coop"] is True
+    hs = search.HostedSearch(bad)
+    hs.begin_instance(seed_root=False)
+    hs.adopt_incumbent(upper, marker)
+    root = bad.work._make_root()
+    hs.add_leaf(root.l[-30:], root.u[-30:], x0, np.zeros(150), 0, -np.inf)
+    hs.run()
+    fs = bad.work.solver.factor_stats()
+    assert fs["coop"] is False and fs["coop_fallbacks"] >= 1  # the launch was called off and redone
+    val, x = bad.work.solver.search_get_incumbent()
+    assert val == upper
+    np.testing.assert_array_equal(x, marker)
 
 
 def test_hosted_search_random_sweep():
@@ -1453,23 +1634,25 @@ def test_two_pools_on_one_gpu_share_one_tree(driver):
         mp.update_vectors(q=q2)
 
 
-def test_streaming_batch_at_config3_size():
+def test_streaming_batch_at_config3_size(oracle_mod):
     """BASELINE config 3 as a stream: n=500, 256 columns kept full from the device-resident pool; a sample of the
-    decided nodes is replayed through solve_node; the columns stay busy (no wave tail)."""
+    decided nodes is replayed through solve_node, and a sample of THOSE through the CPU oracle (status, iterations,
+    x, y, bound); the columns stay busy (no wave tail)."""
     from miosqp_amd import bnb, stream
     pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
     st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 9)
     model = bnb.MIOSQP()
     model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
                 dict(problems.QP_SETTINGS, max_batch=256))
-    seen = []
-    srch = stream.StreamSearch(model, columns=256, observer=_stream_checker(pr, 16, seen))
+    seen, oseen = [], []
+    srch = stream.StreamSearch(model, columns=256, observer=_stream_checker(pr, 16, seen, oracle_mod=oracle_mod,
+                                                                            oracle_stride=3, oracle_seen=oseen))
     eng = model.work.solver
     alive, steps = 1, 0
     while alive and steps < 1500 and srch.nodes < 600:  # the frontier doubles every ~20 chunks (one node's iterations)
         alive = srch.step()
         steps += 1
-    assert srch.nodes >= 256 and len(seen) >= 16
+    assert srch.nodes >= 256 and len(seen) >= 16 and len(oseen) >= 5
     ms, lock_iters, node_iters = eng.batch_stats()
     assert lock_iters == 25 * srch.chunks or lock_iters == 25 * (srch.chunks - 1)
     # useful column-iterations / (columns x lock-step iterations): the stream keeps the columns busy once the

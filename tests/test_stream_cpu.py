@@ -73,7 +73,7 @@ def test_pool_exhaustion_is_loud():
 
 
 def test_several_pools_share_one_tree():
-    """stream.MultiPoolSearch: two / three pools (threads of this process, dist.ThreadComm) on one tree end with the
+    """stream.MultiPoolSearch: two / three pools (threads of this process, poolcomm.PoolComm) on one tree end with the
     sequential optimum; a second instance reuses them."""
     import digest_backend
     from miosqp_amd import bnb, problems, stream

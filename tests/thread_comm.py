@@ -1,2 +1,2 @@
-"""In-process stand-in for a torch.distributed group (moved to miosqp_amd.dist; kept here for the tests' imports)."""
-from miosqp_amd.dist import ThreadComm, ThreadWorld  # noqa: F401
+"""The in-process communicator under the names the CPU tests use (ranks = threads of one process)."""
+from miosqp_amd.poolcomm import PoolComm as ThreadComm, PoolWorld as ThreadWorld  # noqa: F401
