@@ -1495,7 +1495,6 @@ def test_called_off_launch_leaves_slot_children_and_incumbent_alone(monkeypatch)
     start is integral and cheaper than the incumbent -- the epilogue of the called-off launch took it for an
     integer-feasible solution and overwrote the incumbent's x on the device while the host (rightly) discarded the
     record, so the x handed out at the end no longer belonged to upper_glob."""
-    import scipy.sparse.linalg as sla
     from miosqp_amd import bnb, search
     pr = problems.random_miqp(60, 120, 30, seed=11)
     st = dict(problems.BNB_SETTINGS, device_tree=False)
@@ -1505,15 +1504,17 @@ def test_called_off_launch_leaves_slot_children_and_incumbent_alone(monkeypatch)
     r0 = ref.solve()
     assert r0.status == bnb.MI_SOLVED
     n, ii = 60, pr["i_idx"]
-    # an integral point far below the optimum (it ignores the constraints)
-    x0 = sla.spsolve((pr["P"] + 1e-6 * __import__("scipy.sparse").sparse.identity(n)).tocsc(), -pr["q"])
-    x0[ii] = np.clip(np.round(x0[ii]), 0.0, 1.0)
+    # an integral point below the optimum: the optimum's integer part, the continuous part minimised WITHOUT the constraints
+    cset = np.array([i for i in range(n) if i not in set(ii.tolist())])
+    Pd = pr["P"].toarray()
+    x0 = r0.x.copy()
+    x0[cset] = np.linalg.solve(Pd[np.ix_(cset, cset)] + 1e-9 * np.eye(len(cset)),
+                               -(pr["q"][cset] + Pd[np.ix_(cset, ii)].dot(x0[ii])))
     obj0 = 0.5 * x0.dot(pr["P"].dot(x0)) + pr["q"].dot(x0)
     assert obj0 < r0.upper_glob - 1e-3
     upper = 0.5 * (obj0 + r0.upper_glob)  # below every feasible point: nothing the search finds can replace it
     marker = r0.x.copy()
-    cont = [i for i in range(n) if i not in set(ii.tolist())][0]
-    marker[cont] += 0.125
+    marker[cset[0]] += 0.125
     monkeypatch.setenv("MIOSQP_COOP_NAP", "12")
     monkeypatch.setenv("MIOSQP_COOP_DBG", "64")  # workgroup 1 never shows up: the first launch is called off
     bad = bnb.MIOSQP()
