@@ -71,7 +71,13 @@ typedef struct miosqp_qp_settings {
   int32_t coop;              /* -1 auto, 0 off, 1 on: cooperative register-resident solver -- the explicit KKT
                                 inverse (n+M)^2 spread over the register files of up to one workgroup per
                                 CU, ONE exchange per iteration (n+M <= 2048; auto from n+M = 193 on) */
-  int32_t reserved[2];
+  int32_t pers;              /* -1 auto, 0 off, 1 on: persistent streaming solver -- ONE launch per solve that reads the
+                                factor (product or factor form, whichever `fold` selects) from memory in every
+                                iteration; the kernel boundaries of the multi-kernel forms become tagged exchanges
+                                between co-resident workgroups.  Any size that fits one workgroup's LDS operand
+                                buffers (n+M <= ~17 000 in product form, n <= ~9 000 in factor form); auto: problems
+                                beyond the cooperative solver's n+M <= 2048 */
+  int32_t reserved[1];
 } miosqp_qp_settings;
 
 /* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus

@@ -185,6 +185,7 @@ struct Dev {
 #include "kernels_iter.inc"  // device helpers; the four kernels of the factor form and the two of the product form
 #include "kernels_test.inc"  // termination test of the multi-kernel forms (k_check_*), Norms / decide_status shared by all forms
 #include "kernels_coop.inc"  // cooperative register-resident solver (k_coop) and its in-kernel termination test
+#include "kernels_pers.inc"  // persistent streaming solver (k_pers): one launch per solve, the factor read from memory every iteration
 #include "kernels_resident.inc"  // LDS-resident single-workgroup solver (k_resident)
 #include "kernels_node.inc"  // per-solve prologue / epilogue kernels (scaling, warm start, finish, node digest, objective)
 #include "kernels_batched.inc"  // batched mode: sparse row kernels, dense vector-FMA tiles, fp64 matrix-core tiles, batched test
@@ -202,7 +203,7 @@ namespace {
 // the dynamic-LDS ceiling of a kernel is a property of (process, device, kernel): raised to the chip's 160 KB once instead of
 // at every set-up (the call costs ~40 us, a fifth of a small problem's set-up)
 hipError_t lds_limit_once(const void *fn, int which) {
-  static bool done[2][64] = {};
+  static bool done[4][64] = {};
   int dev = 0;
   hipError_t rc = hipGetDevice(&dev);
   if (rc != hipSuccess) return rc;
@@ -237,6 +238,7 @@ int miosqp_qp_default_settings(miosqp_qp_settings *s) {
   s->resident = -1;
   s->setup_on_device = -1;
   s->coop = -1;
+  s->pers = -1;
   return 0;
 }
 
@@ -617,11 +619,21 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       std::vector<double>().swap(e->fo.Pd);
     }
   }
-  tick("product form, resident / cooperative set-up");
+  {
+    // persistent streaming solver (kernels_pers.inc): for what the cooperative solver cannot hold, or on request
+    int want = s->pers;
+    if (const char *ev = getenv("MIOSQP_PERS")) want = atoi(ev);
+    if (want < 0) want = (!e->resident && !e->coop && n + M > 2048) ? 1 : 0;
+    if (want && !e->resident && !e->coop && M > 0) {
+      int rc = pers_setup(e);
+      if (rc) { miosqp_qp_cleanup(e); return rc; }
+    }
+  }
+  tick("product form, resident / cooperative / persistent set-up");
   e->chunk = e->st.check_termination;
   e->tail_iters = e->st.max_iter % e->chunk;
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (!e->resident && !e->coop) {  // the single-launch solvers need no captured chunk
+  if (!e->resident && !e->coop && !e->pers) {  // the single-launch solvers need no captured chunk
     int rc = capture_chunk(e, e->chunk, &e->g_full, &e->x_full);
     if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
     if (rc) { miosqp_qp_cleanup(e); return rc; }
@@ -1066,13 +1078,14 @@ int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z
       int rc = launch_resident(e, k, 0, 0);
       if (rc) return rc;
     }
-  } else if (e->coop) {
+  } else if (e->coop || e->pers) {
     if (k > 0) {
-      launch_coop(e, k, 0, 0);
+      if (e->coop) launch_coop(e, k, 0, 0);
+      else launch_pers(e, k, 0, 0);
       HIPCHK(hipMemcpyAsync(e->h_ctrl, e->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
       if (e->h_ctrl->pad == 1) {  // called off, iterates untouched: the same k iterations in the two-kernel form
-        (void)hipMemsetAsync(e->d.coop_reg, 0, 128 * sizeof(unsigned long long), e->stream);
+        reset_registration(e);
         g_err = "cooperative solver: the grid was not co-resident within 100 ms (device shared?), stage 1";
         int rc = leave_coop(e);
         if (rc) return rc;
@@ -1128,7 +1141,7 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[2] = e->n;
   out[3] = (int64_t)b[4];
   out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0) |
-           ((e->d.coop_nap & 0xff) << 8);
+           (e->pers ? 16 : 0) | ((e->d.coop_nap & 0xff) << 8);
   return 0;
 }
 
@@ -1146,13 +1159,16 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 // debug: per-block (start, end) wall-clock stamps (100 MHz) of ONE launch of a product-form kernel
 int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
                              int32_t *nblocks) {
-  if (!e || !out || !e->fold || which < 0 || which > 3 || (which == 2 && !e->coop) || (which >= 3 && e->Bcap == 0))
+  if (!e || !out || which < 0 || which > 4 || (which < 4 && !e->fold) || (which == 2 && !e->coop) || (which == 3 && e->Bcap == 0) ||
+      (which == 4 && !e->pers))
     return MIOSQP_EARG;
   ENTER(e);
   unsigned long long *buf = nullptr;
   HIPCHK(hipMalloc((void **)&buf, sizeof(unsigned long long) * 2 * 8192));
   HIPCHK(hipMemsetAsync(buf, 0, sizeof(unsigned long long) * 2 * 8192, e->stream));
-  if (which >= 3) {
+  if (which == 4) {
+    launch_pers(e, 20, 0, 0);
+  } else if (which == 3) {
     for (int i = 0; i < 5; i++) launch_iteration_b(e, e->Bcap / 64);
   } else {
     for (int i = 0; i < 20; i++) launch_iteration(e);
@@ -1163,7 +1179,11 @@ int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, 
   // thread 0 in {reduce, update+publish, gather}, iterations, {test operands+rows, test norms}, tests, -
   // which == 3: the batched forward sweep (kbm_fwd) at full width; per workgroup 8 words (100 MHz stamps of wave 0):
   // start, first loads issued, first operands arrived, sweep done, reduced, stored
-  if (which == 3) launch_bd(e, e->Bcap / 64, 0);
+  // which == 4: 1000 iterations of the persistent streaming solver, tests every 25; per workgroup 16 words: shader
+  // clocks of thread 0 in {sparse forward, forward wait, forward rows, forward epilogue, backward wait, backward rows,
+  // backward epilogue (+ sparse backward), tests}, iterations
+  if (which == 4) launch_pers(e, 1000, 25, 0);
+  else if (which == 3) launch_bd(e, e->Bcap / 64, 0);
   else if (which == 2) launch_coop(e, 1000, 25, 0);
   else if (which == 0) launch_fold_fwd(e); else launch_fold_bwd(e);
   e->d = saved;
@@ -1241,10 +1261,10 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
       default: launch_iteration(e); break;
     }
   };
-  if (e->coop && which == 4) {  // `reps` iterations of the cooperative solver in ONE launch, no tests
-    launch_coop(e, 5, 0, 0);
+  if ((e->coop || e->pers) && which == 4) {  // `reps` iterations of the single-launch solver in ONE launch, no tests
+    if (e->coop) launch_coop(e, 5, 0, 0); else launch_pers(e, 5, 0, 0);
     HIPCHK(hipEventRecord(e->ev0, e->stream));
-    launch_coop(e, reps, 0, 0);
+    if (e->coop) launch_coop(e, reps, 0, 0); else launch_pers(e, reps, 0, 0);
     HIPCHK(hipEventRecord(e->ev1, e->stream));
   } else {
     for (int i = 0; i < 5; i++) one();

@@ -478,22 +478,24 @@ def test_batched_search_finds_the_same_optimum():
     np.testing.assert_array_equal(out[0][2][ii], out[1][2][ii])
 
 
-FORMS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 0, 1)]
+# (fold, resident, coop, pers)
+FORMS = [(0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0), (1, 0, 1, 0), (0, 0, 0, 1), (1, 0, 0, 1)]
 
 
-@pytest.mark.parametrize("fold,resident,coop", FORMS)
-def test_both_factor_forms_match_oracle(oracle_mod, fold, resident, coop):
+@pytest.mark.parametrize("fold,resident,coop,pers", FORMS)
+def test_both_factor_forms_match_oracle(oracle_mod, fold, resident, coop, pers):
     """fold=0: factor form L (4 kernels per iteration); fold=1: product form L^-1 (2 kernels);
     resident=1: the whole solve in one LDS-resident workgroup; coop=1: the whole solve in one
-    cooperative launch, explicit KKT inverse in registers, one exchange per iteration."""
+    cooperative launch, explicit KKT inverse in registers, one exchange per iteration; pers=1: the whole solve
+    in one persistent launch that streams the factor (either form) from memory in every iteration."""
     from miosqp_amd import qp
     pr = problems.random_miqp(60, 120, 30, seed=11)
     A, l, u = problems.extended(pr)
     g, o = qp.OSQP(), oracle_mod.OSQP()
-    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, coop=coop, **problems.QP_SETTINGS)
+    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, coop=coop, pers=pers, **problems.QP_SETTINGS)
     o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
     fs = g.factor_stats()
-    assert (fs["fold"], fs["resident"], fs["coop"]) == (bool(fold), bool(resident), bool(coop))
+    assert (fs["fold"], fs["resident"], fs["coop"], fs["pers"]) == (bool(fold), bool(resident), bool(coop), bool(pers))
     rng = np.random.RandomState(3)
     x0, y0 = rng.randn(60), rng.randn(A.shape[0])
     for k in (1, 3, 40):
@@ -633,9 +635,9 @@ def test_setup_rejects_bad_input():
         qp.OSQP().setup(P, np.zeros(3), spa.csc_matrix(np.eye(3)), -np.ones(3), np.ones(3), adaptive_rho=True)
 
 
-@pytest.mark.parametrize("fold,resident,coop", FORMS)
+@pytest.mark.parametrize("fold,resident,coop,pers", FORMS)
 @pytest.mark.parametrize("max_iter,check", [(60, 25), (50, 0), (30, 7), (25, 25), (3, 1)])
-def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, coop, max_iter, check):
+def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, coop, pers, max_iter, check):
     """MAX_ITER_REACHED, a tail chunk shorter than the cadence, cadence 1, and the test switched off:
     status, iteration count and iterates equal the oracle's in every engine form."""
     from miosqp_amd import qp
@@ -643,7 +645,7 @@ def test_iteration_limits_and_test_cadence(oracle_mod, fold, resident, coop, max
     A, l, u = problems.extended(pr)
     kw = dict(problems.QP_SETTINGS, max_iter=max_iter, check_termination=check, eps_abs=1e-9, eps_rel=1e-9)
     g, o = qp.OSQP(), oracle_mod.OSQP()
-    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, coop=coop, **kw)
+    g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=resident, coop=coop, pers=pers, **kw)
     o.setup(pr["P"], pr["q"], A, l, u, **kw)
     x0, y0 = np.full(40, 0.3), np.zeros(A.shape[0])
     g.warm_start(x=x0, y=y0)
