@@ -203,7 +203,7 @@ namespace {
 // the dynamic-LDS ceiling of a kernel is a property of (process, device, kernel): raised to the chip's 160 KB once instead of
 // at every set-up (the call costs ~40 us, a fifth of a small problem's set-up)
 hipError_t lds_limit_once(const void *fn, int which) {
-  static bool done[4][64] = {};
+  static bool done[5][64] = {};
   int dev = 0;
   hipError_t rc = hipGetDevice(&dev);
   if (rc != hipSuccess) return rc;

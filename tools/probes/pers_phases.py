@@ -15,7 +15,7 @@ g.warm_start(x=np.zeros(n), y=np.zeros(A.shape[0]))
 lib = _lib.load()
 G = 256
 names = ["sparse fwd", "fwd wait", "fwd rows", "fwd epilogue", "bwd wait", "bwd rows", "bwd epilogue(+sparse)", "tests"]
-for rep in range(2):
+for rep in range(1):
     out = np.zeros(16 * G, dtype=np.uint64); nb = C.c_int32()
     rc = lib.miosqp_qp_debug_timeline(g._h, 4, out.ctypes.data_as(C.POINTER(C.c_uint64)), 8 * G, C.byref(nb))
     o = out.reshape(G, 16).astype(np.float64)
@@ -30,3 +30,9 @@ for rep in range(2):
     print("  sum of medians %.0f clocks" % tot)
 us, by = g.time_kernel(4, 1000)
 print("time_kernel: %.2f us / iteration" % us)
+# per-XCD view of the two row phases (workgroup b runs on XCD b % 8)
+for k in (2, 5):
+    v = o[live, k] / it
+    idx = np.arange(G)[live]
+    print("  %-10s by XCD:" % names[k], " ".join("%6.0f" % np.median(v[idx % 8 == x]) for x in range(8)))
+    print("  %-10s by workgroup octile:" % names[k], " ".join("%6.0f" % np.median(v[(idx // 32) == x]) for x in range(8)))
