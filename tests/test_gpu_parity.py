@@ -948,6 +948,58 @@ def test_randomised_sweep_over_shapes_forms_and_bounds(oracle_mod):
     assert len({s[:3] for s in seen}) >= 4 and len({s[3] for s in seen}) >= 2, seen
 
 
+def test_persistent_solver_random_sweep(oracle_mod):
+    """80 random instances on the persistent streaming solver, both factor forms (and so all three kernels: lean product
+    form, general product form for the larger ones, factor form): shapes from 4 variables up -- rows shorter than a wave,
+    odd sizes, workgroups without a constraint row --, densities from 5 % to full, random warm starts, bounds randomly
+    tightened or opened to infinity (infeasible relaxations among them): status, iteration count and solution equal
+    the oracle's.  (The first version read its LDS operand out of range for segments shorter than 128 columns: any such
+    slip shows up here as a NaN or a wrong count.)"""
+    import scipy.sparse as spa
+    from miosqp_amd import qp
+    rng = np.random.RandomState(77)
+    kinds = set()
+    for trial in range(80):
+        big = trial % 10 == 9
+        n = int(rng.randint(150, 400)) if big else int(rng.randint(4, 70))
+        m = int(rng.randint(100, 900)) if big else int(rng.randint(1, 120))
+        p = int(rng.randint(0, n + 1))
+        dens = float(rng.choice([0.05, 0.2, 0.7, 1.0]))
+        pr = problems.random_miqp(n, m, p, density=dens, seed=5000 + trial)
+        A, l, u = problems.extended(pr)
+        A = spa.csc_matrix(A)
+        M = A.shape[0]
+        l, u = l.copy(), u.copy()
+        for j in rng.choice(M, size=min(M, 4), replace=False):
+            mode = int(rng.randint(0, 4))
+            if mode == 0:
+                u[j] = np.inf
+            elif mode == 1:
+                l[j] = -np.inf
+            else:
+                c0 = 0.5 * (l[j] + u[j]) if np.isfinite(l[j]) and np.isfinite(u[j]) else 0.0
+                w = float(rng.choice([0.0, 0.05, 1.0]))
+                l[j], u[j] = c0 - w + rng.randn() * 0.5, c0 + w + rng.randn() * 0.5
+                if l[j] > u[j]:
+                    l[j], u[j] = u[j], l[j]
+        fold = int(rng.randint(0, 2))
+        g, o = qp.OSQP(), oracle_mod.OSQP()
+        g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=0, coop=0, pers=1, **problems.QP_SETTINGS)
+        o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+        fs = g.factor_stats()
+        assert fs["pers"] is True, (trial, n, m, p)
+        x0, y0 = rng.randn(n) * rng.choice([0.0, 1.0]), rng.randn(M) * rng.choice([0.0, 1.0])
+        g.warm_start(x=x0, y=y0)
+        o.warm_start(x=x0, y=y0)
+        rg, ro = g.solve(), o.solve()
+        kinds.add((fold, ro.info.status_val))
+        assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), (trial, n, m, p, dens, fold)
+        np.testing.assert_allclose(rg.x, ro.x, rtol=1e-6, atol=1e-7, equal_nan=True, err_msg=str((trial, fold)))
+        np.testing.assert_allclose(rg.y, ro.y, rtol=1e-6, atol=1e-7, equal_nan=True, err_msg=str((trial, fold)))
+        g.close()
+    assert len({k[0] for k in kinds}) == 2 and len({k[1] for k in kinds}) >= 2, kinds
+
+
 def test_cooperative_solver_reports_a_missing_workgroup_and_recovers(oracle_mod, monkeypatch):
     """Fault injection: one workgroup of the cooperative launch never starts (what a co-tenant on the device
     does to it).  Workgroup 0 calls the launch off after ~100 ms, before any iterate has been touched; the
@@ -1010,6 +1062,94 @@ def test_cooperative_solver_reports_a_missing_workgroup_and_recovers(oracle_mod,
     rg, ro = g.solve(), o.solve()
     assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
     assert rel(rg.x, ro.x) <= SOL_TOL
+
+
+def test_persistent_solver_reports_a_missing_workgroup_and_recovers(monkeypatch):
+    """The fault of the test above on the persistent streaming solver (both kernels: the lean product-form one and the
+    general one in factor form): the launch is called off before any iterate is touched, the same call is redone in the
+    multi-kernel form -- bit-identical to an engine that never was persistent --, the engine stays there."""
+    import time
+    from miosqp_amd import qp
+    pr = problems.random_miqp(60, 120, 30, seed=11)
+    A, l, u = problems.extended(pr)
+    x0, y0 = np.zeros(60), np.zeros(A.shape[0])
+    for fold in (1, 0):
+        monkeypatch.setenv("MIOSQP_COOP_DBG", "64")
+        bad = qp.OSQP()
+        bad.setup(pr["P"], pr["q"], A, l, u, fold=fold, coop=0, resident=0, pers=1, **problems.QP_SETTINGS)
+        monkeypatch.delenv("MIOSQP_COOP_DBG")
+        ref = qp.OSQP()
+        ref.setup(pr["P"], pr["q"], A, l, u, fold=fold, coop=0, resident=0, pers=0, **problems.QP_SETTINGS)
+        assert bad.factor_stats()["pers"] is True and ref.factor_stats()["pers"] is False
+        for s_ in (bad, ref):
+            s_.warm_start(x=x0, y=y0)
+        t0 = time.time()
+        r_bad = bad.solve()
+        assert time.time() - t0 < 1.5
+        r_ref = ref.solve()
+        fs = bad.factor_stats()
+        assert fs["pers"] is False and fs["coop_fallbacks"] == 1
+        assert (r_bad.info.status_val, r_bad.info.iter) == (r_ref.info.status_val, r_ref.info.iter)
+        np.testing.assert_array_equal(r_bad.x, r_ref.x)
+        np.testing.assert_array_equal(r_bad.y, r_ref.y)
+        bad.close()
+        ref.close()
+
+
+def test_persistent_kernels_agree_and_take_sizes_beyond_the_cooperative_grid(oracle_mod, monkeypatch):
+    """(a) The lean product-form kernel (one dense task per wave and phase) and the general kernel run the same arithmetic in
+    the same order: bit-identical iterates and solutions.  (b) n + M = 2450 > 2048 -- beyond what the cooperative solver
+    holds in registers -- takes the persistent form by itself, in either factor form, and matches the oracle: status,
+    iteration count, x, y (iterates after 1, 10 and 40 iterations to 1e-9)."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(130, 260, 65, seed=3)
+    A, l, u = problems.extended(pr)
+    lean = qp.OSQP()
+    lean.setup(pr["P"], pr["q"], A, l, u, fold=1, coop=0, resident=0, pers=1, **problems.QP_SETTINGS)
+    monkeypatch.setenv("MIOSQP_PERS_GENERAL", "1")
+    gen = qp.OSQP()
+    gen.setup(pr["P"], pr["q"], A, l, u, fold=1, coop=0, resident=0, pers=1, **problems.QP_SETTINGS)
+    monkeypatch.delenv("MIOSQP_PERS_GENERAL")
+    rng = np.random.RandomState(1)
+    xw, yw = rng.randn(130), rng.randn(A.shape[0])
+    for k in (1, 7, 60):
+        for s_ in (lean, gen):
+            s_.warm_start(x=xw, y=yw)
+        a, b = lean.debug_iterate(k), gen.debug_iterate(k)
+        for va, vb in zip(a, b):
+            np.testing.assert_array_equal(va, vb)
+    for s_ in (lean, gen):
+        s_.warm_start(x=np.zeros(130), y=np.zeros(A.shape[0]))
+    ra, rb = lean.solve(), gen.solve()
+    assert (ra.info.status_val, ra.info.iter) == (rb.info.status_val, rb.info.iter)
+    np.testing.assert_array_equal(ra.x, rb.x)
+    np.testing.assert_array_equal(ra.y, rb.y)
+    lean.close()
+    gen.close()
+    pr = problems.random_miqp(700, 1400, 350, density=0.3, seed=5)
+    A, l, u = problems.extended(pr)
+    n, M = 700, A.shape[0]
+    o = oracle_mod.OSQP()
+    o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    xw, yw = rng.randn(n), rng.randn(M)
+    for fold in (1, 0):
+        g = qp.OSQP()
+        g.setup(pr["P"], pr["q"], A, l, u, fold=fold, **problems.QP_SETTINGS)
+        fs = g.factor_stats()
+        assert fs["pers"] is True and fs["coop"] is False and fs["fold"] == bool(fold)
+        for k in (1, 10, 40):
+            g.warm_start(x=xw, y=yw)
+            o.warm_start(x=xw, y=yw)
+            xg, zg, yg = g.debug_iterate(k)
+            o.iterate(k)
+            xo, zo, yo = o.iterates()
+            assert rel(xg, xo) <= ITER_TOL and rel(zg, zo) <= ITER_TOL and rel(yg, yo) <= ITER_TOL, (fold, k)
+        g.warm_start(x=np.zeros(n), y=np.zeros(M))
+        o.warm_start(x=np.zeros(n), y=np.zeros(M))
+        rg, ro = g.solve(), o.solve()
+        assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), fold
+        assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL
+        g.close()
 
 
 def test_engine_driven_from_a_worker_thread():
@@ -1437,7 +1577,8 @@ def test_native_stream_driver_reaches_the_reference_optimum(name):
             np.testing.assert_array_equal(g["x"][ii], e["x"][ii])
 
 
-@pytest.mark.parametrize("form", [dict(coop=0, resident=0), dict(fold=0, coop=0, resident=0), dict(resident=1)])
+@pytest.mark.parametrize("form", [dict(coop=0, resident=0), dict(fold=0, coop=0, resident=0), dict(resident=1),
+                                  dict(coop=0, resident=0, pers=1), dict(fold=0, coop=0, resident=0, pers=1)])
 def test_hosted_search_on_every_engine_form(form):
     """The hosted loop drives whatever form the engine uses for single nodes (two-kernel product form with host-checked
     chunks, four-kernel factor form, LDS-resident workgroup): same nodes and iterations as the Python loop on that form;
