@@ -19,8 +19,9 @@ ranks (miosqp_amd/dist.py), one process per GPU, RCCL only for the incumbent: we
 
 Extra legs in the same JSON line (none of them is part of `value`):
   batched   BASELINE configs[2]: waves of up to 256 leaves per device call
-  stream    the same node-at-a-time workload on the HBM-STREAMING form of the engine (factor re-read from
-            HBM every iteration, two launches per iteration) -- what the north star's roofline is about
+  stream    the same node-at-a-time workload on the STREAMING forms of the engine (factor re-read from memory every
+            iteration): the persistent solver (one launch per node) and the two-launch form beside it -- what the
+            north star's roofline is about
   config5   BASELINE configs[4]: n=5000, the bandwidth-bound single-node case
   config4   BASELINE configs[3]: the power-converter MPC sequence (40 MIQPs, n=18)
   config1   BASELINE configs[0]: n=50 (the reference's CPU-runnable size), whole trees, with the CPU oracle beside it
@@ -55,7 +56,12 @@ def pmc_traffic(kernel, tag=""):
     if not files:
         return None, None
     try:
-        kernels = json.load(open(files[-1]))["kernels"]
+        rec = json.load(open(files[-1]))
+        from miosqp_amd import _lib
+        if rec.get("source_digest") != _lib.source_digest():
+            return None, "profiles/%s is of other device code (source digest %s, now %s): not used" % (
+                os.path.basename(files[-1]), rec.get("source_digest"), _lib.source_digest())
+        kernels = rec["kernels"]
         for name in sorted(kernels):  # template instances are listed as "name<...>"
             if name == kernel or name.startswith(kernel + "<"):
                 return kernels[name]["traffic_bytes"], "profiles/" + os.path.basename(files[-1])
@@ -86,60 +92,13 @@ def setup_model(prob, qs, st=None, backend=None):
     return model, time.time() - t0
 
 
-def large_leg(seed, device, nodes=12):
-    """BASELINE configs[4] (random_miqp n=5000 m=10000 p=2500, 1 % dense A, fp64): the single-node iteration
-    is HBM-bandwidth-bound.  Two byte conventions side by side: SURVEY sec. 8d's (12 B per factor entry, value +
-    index: 317 MB per iteration) and what the kernels really request (the dense tail has no index array: 8 B
-    per entry, ~217 MB)."""
-    from miosqp_amd import dist, problems
-    cfg = problems.CONFIGS["cfg5"]
-    prob = problems.random_miqp(seed=seed, **cfg)
-    model, setup_s = setup_model(prob, dict(problems.QP_SETTINGS, device=device))
+def _node_run(model, nodes, warm):
+    """`nodes` node relaxations of the model's tree, one at a time (HIP events around every ADMM loop): per-iteration
+    device time of the timed region, iterations, nodes, wall rates."""
+    from miosqp_amd import dist
     eng = model.work.solver
     srch = dist.ShardedSearch(model)
-    srch.step(1)
-    eng.loop_stats(reset=True)
-    n0, i0 = srch.nodes, srch.iters
-    t0 = time.perf_counter()
-    for _ in range(nodes):
-        srch.step(1)
-    dt = time.perf_counter() - t0
-    ms, it = eng.loop_stats()
-    fs = eng.factor_stats()
-    us = 1e3 * ms / max(1, it)
-    kern = []
-    for k, nm in enumerate(KERNELS):
-        kus, kby = eng.time_kernel(k, 100)
-        kern.append(dict(kernel=nm, usec=round(kus, 2), bytes_sec8d=kby))
-    tr, src = pmc_traffic("k_tail_fwd", "_cfg5")
-    out = dict(workload="random_miqp n=%d m=%d p=%d density %.2f, node-at-a-time" %
-                        (cfg["n"], cfg["m"], cfg["p"], cfg["density"]),
-               iters_per_s=round((srch.iters - i0) / dt, 1), nodes_per_s=round((srch.nodes - n0) / dt, 2),
-               nnz_L=fs["nnz_L"], setup_s=round(setup_s, 2), usec_per_iter=round(us, 2),
-               bytes_per_iter=fs["bytes_per_iter"], achieved_gbs=round(fs["bytes_per_iter"] / us * 1e-3, 1),
-               frac=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
-               bytes_moved_per_iter=fs["bytes_moved_per_iter"],
-               moved_gbs=round(fs["bytes_moved_per_iter"] / us * 1e-3, 1),
-               moved_frac=round(fs["bytes_moved_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
-               bound="hbm", factor_form="L (4 launches/iteration)", kernels_back_to_back=kern,
-               note="frac uses SURVEY 8d's 12 B per factor entry; moved_frac the 8 B per entry the dense tail "
-                    "kernels really request")
-    if tr is not None:
-        out["pmc_traffic_k_tail_fwd"] = dict(bytes_per_launch=tr, source=src)
-    eng.close()
-    return out
-
-
-def stream_leg(prob, device, nodes=40):
-    """The HBM-streaming form of the engine on the headline workload: product-form factor stored once in HBM and
-    re-read by every iteration (k_fold_fwd / k_fold_bwd, two launches per iteration).  This is the form the
-    north star's "achieved HBM GB/s against the 8 TB/s roofline" is about, the form every problem with
-    n + M > 2048 runs in, and what a cooperative engine falls back to on a shared device."""
-    from miosqp_amd import dist, problems
-    model, setup_s = setup_model(prob, dict(problems.QP_SETTINGS, device=device, coop=0))
-    eng = model.work.solver
-    srch = dist.ShardedSearch(model)
-    for _ in range(5):
+    for _ in range(warm):
         srch.step(1)
     eng.loop_stats(reset=True)
     n0, i0 = srch.nodes, srch.iters
@@ -149,24 +108,114 @@ def stream_leg(prob, device, nodes=40):
             break
     dt = time.perf_counter() - t0
     ms, it = eng.loop_stats()
-    fs = eng.factor_stats()
-    us = 1e3 * ms / max(1, it)
-    kern = []
-    for k, nm in enumerate(["k_fold_fwd", "k_fold_bwd"]):
-        kus, kby = eng.time_kernel(k, 300)
-        tr, src = pmc_traffic(nm, "_two_kernel_form")
-        rec = dict(kernel=nm, usec=round(kus, 3), bytes=kby, gbs=round(kby / kus * 1e-3, 1))
-        if tr is not None:
-            rec.update(traffic=tr, hbm_measured_gbs=round(tr / kus * 1e-3, 1), traffic_source=src)
-        kern.append(rec)
-    out = dict(workload="the headline workload on the HBM-streaming engine form (coop=0)",
-               factor_form="product form L^-1 in HBM, 2 launches/iteration", bound="hbm",
-               iters_per_s=round((srch.iters - i0) / dt, 1), nodes_per_s=round((srch.nodes - n0) / dt, 2),
-               usec_per_iter=round(us, 3), bytes_per_iter=fs["bytes_per_iter"],
-               achieved_gbs=round(fs["bytes_per_iter"] / us * 1e-3, 1),
-               frac=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4), kernels_back_to_back=kern,
-               setup_s=round(setup_s, 3))
-    eng.close()
+    return dict(usec_per_iter=1e3 * ms / max(1, it), iters=srch.iters - i0, nodes=srch.nodes - n0, dt=dt,
+                launches=srch.nodes - n0, loop_ms=ms, loop_iters=it)
+
+
+def large_leg(seed, device, nodes=12):
+    """BASELINE configs[4] (random_miqp n=5000 m=10000 p=2500, 1 % dense A, fp64): the single-node iteration
+    is HBM-bandwidth-bound.  The engine's form for this size is the persistent streaming solver on the factor form
+    (one launch per node; `four_launch_form`: the same nodes with four launches per iteration beside it).  Two byte
+    conventions side by side: SURVEY sec. 8d's (12 B per factor entry, value + index: 317 MB per iteration) and
+    what the kernels really request (the dense tail has no index array: 8 B per entry, ~217 MB)."""
+    from miosqp_amd import problems
+    cfg = problems.CONFIGS["cfg5"]
+    prob = problems.random_miqp(seed=seed, **cfg)
+    out = None
+    for pers in (-1, 0):
+        model, setup_s = setup_model(prob, dict(problems.QP_SETTINGS, device=device, pers=pers))
+        eng = model.work.solver
+        fs = eng.factor_stats()
+        r = _node_run(model, nodes, 1)
+        us = r["usec_per_iter"]
+        rec = dict(iters_per_s=round(r["iters"] / r["dt"], 1), nodes_per_s=round(r["nodes"] / r["dt"], 2),
+                   usec_per_iter=round(us, 2), usec_back_to_back=round(eng.time_kernel(4, 100)[0], 2),
+                   achieved_gbs=round(fs["bytes_per_iter"] / us * 1e-3, 1),
+                   frac=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
+                   moved_gbs=round(fs["bytes_moved_per_iter"] / us * 1e-3, 1),
+                   moved_frac=round(fs["bytes_moved_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
+                   setup_s=round(setup_s, 2))
+        if fs["pers"]:
+            rec.update(factor_form="L, read from memory every iteration, ONE persistent launch per node (k_pers<false>)",
+                       kernel="k_pers<false>", launches=r["launches"],
+                       iterations_per_launch=round(r["loop_iters"] / max(1, r["launches"]), 1),
+                       usec_per_launch=round(1e3 * r["loop_ms"] / max(1, r["launches"]), 1))
+            tr, src = pmc_traffic("k_pers<false>", "_cfg5")
+            if tr is not None:
+                rec["pmc_traffic"] = dict(bytes_per_launch=tr, source=src,
+                                          hbm_measured_gbs=round(tr / (1e3 * r["loop_ms"] / max(1, r["launches"])) * 1e-3, 1))
+        else:
+            kern = []
+            for k, nm in enumerate(KERNELS):
+                kus, kby = eng.time_kernel(k, 100)
+                kern.append(dict(kernel=nm, usec=round(kus, 2), bytes_sec8d=kby))
+            rec.update(factor_form="L (4 launches/iteration)", kernels_back_to_back=kern)
+        if out is None:
+            out = dict(workload="random_miqp n=%d m=%d p=%d density %.2f, node-at-a-time" %
+                                (cfg["n"], cfg["m"], cfg["p"], cfg["density"]),
+                       nnz_L=fs["nnz_L"], bytes_per_iter=fs["bytes_per_iter"], bytes_moved_per_iter=fs["bytes_moved_per_iter"],
+                       bound="hbm",
+                       note="frac uses SURVEY 8d's 12 B per factor entry; moved_frac the 8 B per entry the dense tail "
+                            "rows really request; usec_per_iter: HIP events around the ADMM loops of the timed nodes "
+                            "(tests included), usec_back_to_back: iterations only")
+            out.update(rec)
+            if not fs["pers"]:
+                eng.close()
+                break
+        else:
+            out["four_launch_form"] = rec
+        eng.close()
+    return out
+
+
+def stream_leg(prob, device, nodes=40):
+    """The HBM / L2-STREAMING form of the engine on the headline workload: product-form factor stored once in HBM and
+    re-read by every iteration -- what the north star's "achieved GB/s against the 8 TB/s roofline" is about, and the
+    form of every problem beyond the cooperative solver's n + M <= 2048.  Headline of the leg: the persistent streaming
+    solver (ONE launch per node, k_pers_small at this size); `two_launch_form`: k_fold_fwd / k_fold_bwd, two launches
+    per iteration, on the same nodes -- also what a single-launch engine falls back to on a shared device."""
+    from miosqp_amd import problems
+    out = None
+    for pers in (1, 0):
+        model, setup_s = setup_model(prob, dict(problems.QP_SETTINGS, device=device, coop=0, pers=pers))
+        eng = model.work.solver
+        fs = eng.factor_stats()
+        r = _node_run(model, nodes, 5)
+        us = r["usec_per_iter"]
+        rec = dict(iters_per_s=round(r["iters"] / r["dt"], 1), nodes_per_s=round(r["nodes"] / r["dt"], 2),
+                   usec_per_iter=round(us, 3), usec_back_to_back=round(eng.time_kernel(4, 1000 if fs["pers"] else 100)[0], 3),
+                   achieved_gbs=round(fs["bytes_per_iter"] / us * 1e-3, 1),
+                   frac=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4), setup_s=round(setup_s, 3))
+        if fs["pers"]:
+            rec.update(factor_form="product form L^-1 read from memory (L2 at this size) every iteration, ONE persistent "
+                                   "launch per node", kernel="k_pers_small", launches=r["launches"],
+                       iterations_per_launch=round(r["loop_iters"] / max(1, r["launches"]), 1),
+                       usec_per_launch=round(1e3 * r["loop_ms"] / max(1, r["launches"]), 1))
+            tr, src = pmc_traffic("k_pers_small", "_persistent")
+            if tr is not None:
+                rec["pmc_traffic"] = dict(bytes_per_launch=tr, source=src)
+        else:
+            kern = []
+            for k, nm in enumerate(["k_fold_fwd", "k_fold_bwd"]):
+                kus, kby = eng.time_kernel(k, 300)
+                krec = dict(kernel=nm, usec=round(kus, 3), bytes=kby, gbs=round(kby / kus * 1e-3, 1))
+                tr, src = pmc_traffic(nm, "_two_kernel_form")
+                if tr is not None:
+                    krec.update(traffic=tr, hbm_measured_gbs=round(tr / kus * 1e-3, 1), traffic_source=src)
+                kern.append(krec)
+            rec.update(factor_form="product form L^-1 in HBM, 2 launches/iteration", kernels_back_to_back=kern)
+        if out is None:
+            out = dict(workload="the headline workload on the streaming engine forms (coop=0)", bound="hbm",
+                       bytes_per_iter=fs["bytes_per_iter"],
+                       note="usec_per_iter: HIP events around the ADMM loops of the timed nodes (tests included); "
+                            "usec_back_to_back: iterations only")
+            out.update(rec)
+            if not fs["pers"]:
+                eng.close()
+                break
+        else:
+            out["two_launch_form"] = rec
+        eng.close()
     return out
 
 
@@ -662,6 +711,12 @@ def main():
             kern.append(dict(kernel="k_coop", usec=round(us, 3), bytes=round(by), gbs=round(by / max(us, 1e-9) * 1e-3, 1),
                              launches=launches, iterations_per_launch=round(loop_iters / launches, 1)))
             it_us, it_bytes = (0.0, 0.0) if args.no_probes else eng.time_kernel(4, 2000)
+        elif fs["pers"]:  # likewise one launch per node
+            launches = max(1, nodes_here)
+            us, by = 1e3 * loop_ms / launches, fs["bytes_per_iter"] * loop_iters / launches
+            kern.append(dict(kernel="k_pers", usec=round(us, 3), bytes=round(by), gbs=round(by / max(us, 1e-9) * 1e-3, 1),
+                             launches=launches, iterations_per_launch=round(loop_iters / launches, 1)))
+            it_us, it_bytes = (0.0, 0.0) if args.no_probes else eng.time_kernel(4, 200)
         else:
             names = ["k_fold_fwd", "k_fold_bwd"] if fs["fold"] else KERNELS
             if args.no_probes:  # no extra launches: the whole iteration from the loop's own events
@@ -684,8 +739,8 @@ def main():
         roof = dict(bound="exchange-latency" if fs["coop"] else "hbm",
                     roofline="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic,
-                    traffic_source=("committed profile %s (separate rocprofv3 --pmc passes of a node-only run; "
-                                    "not measured in this run)" % tsrc) if tsrc else None,
+                    traffic_source=(("committed profile %s (separate rocprofv3 --pmc passes of a node-only run of the same "
+                                     "device code; not measured in this run)" % tsrc) if traffic else tsrc) if tsrc else None,
                     hbm_measured_gbs=round(traffic / dom["usec"] * 1e-3, 1) if traffic else None,
                     bytes_per_launch=dom["bytes"], usec_per_launch=dom["usec"], kernels=kern,
                     iteration=dict(bytes=fs["bytes_per_iter"],
@@ -712,7 +767,8 @@ def main():
                                          else "%d node(s)" % args.wave, world),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
                                factor_form="explicit KKT inverse in registers, cooperative launch per node"
-                               if fs["coop"] else "product form L^-1 (2 launches/iteration)" if fs["fold"]
+                               if fs["coop"] else ("product form L^-1" if fs["fold"] else "L") + ", persistent streaming launch per node"
+                               if fs["pers"] else "product form L^-1 (2 launches/iteration)" if fs["fold"]
                                else "L (4 launches/iteration)",
                                qp_settings=problems.QP_SETTINGS, rho=0.1, setup_s=round(t_setup, 3),
                                coop_fallbacks=fs["coop_fallbacks"], replicated_resyncs=srch.resyncs,

@@ -138,3 +138,18 @@ def as_d(a):
 
 def as_i(a):
     return a.ctypes.data_as(ip)
+
+
+def source_digest():
+    """16 hex digits identifying the device code (csrc/*.hip, *.inc, *.cpp, *.hpp): written into the PMC summaries under
+    profiles/ by tools/pmc_merge.py and compared by bench.py, so that counter traffic of other code is not mixed with
+    today's timing."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_PKG, "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*"))):
+        if f.endswith((".hip", ".inc", ".cpp", ".hpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
