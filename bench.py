@@ -255,6 +255,23 @@ def mpc_leg(device, repeats=3):
                device_usec_per_node=round(1e3 * ms / max(1, nodes), 1),
                matches_reference_fixture=bool(ok),
                bound="latency (8 KB of factor: LDS-resident, the HBM roofline does not apply)")
+    # the same 40 MIQPs as ONE launch of 40 single-wavefront trees (MIOSQP.solve_many / miosqp_qp_solve_trees): what
+    # independent instances on one factorisation cost when the chip is not left to one wavefront -- e.g. a batch of
+    # scenarios per sampling instant; the closed loop itself is sequential (each step needs the previous one's input)
+    inst = [dict(q=pc["q"][k].copy(), l=pc["l"].copy(), u=pc["u"][k].copy(), x0=pc["x0"][k].copy()) for k in range(len(pc["q"]))]
+    got = model.solve_many(inst)  # warm-up + parity
+    okb = all(g["nodes"] == int(pc["nodes"][k]) and g["osqp_iter"] == int(pc["osqp_iter"][k]) for k, g in enumerate(got))
+    reps_b = 20
+    tb = time.perf_counter()
+    for _ in range(reps_b):
+        inst_b = inst * 4  # 160 trees per launch
+        got = model.solve_many(inst_b)
+    dtb = time.perf_counter() - tb
+    nb = reps_b * len(inst_b)
+    out["batched"] = dict(what="MIOSQP.solve_many: %d independent MIQPs per launch, one wavefront each" % len(inst_b),
+                          mpc_steps_per_s=round(nb / dtb, 1), usec_per_mpc_step=round(1e6 * dtb / nb, 2),
+                          nodes_per_s=round(sum(g["nodes"] for g in got) * reps_b / dtb, 1),
+                          matches_reference_fixture=bool(okb))
     eng.close()
     return out
 
@@ -300,10 +317,31 @@ def small_leg(seed, device, instances=40):
         res[name + "_uppers"] = uppers
         if backend is None:
             model.work.solver.close()
+    # the same sequence as batches of 64 trees per launch (MIOSQP.solve_many: a workgroup per MIQP)
+    model = bnb.MIOSQP()
+    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"], prob["i_u"],
+                dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS, device=device))
+    rng = np.random.RandomState(seed + 4242)
+    inst = [dict(q=rng.randn(cfg["n"]), l=-2 + rng.rand(cfg["m"]), u=2 + rng.rand(cfg["m"])) for _ in range(instances + 3)]
+    Bt = 64
+    many = (inst[3:] * ((4 * Bt) // max(1, instances) + 1))[:4 * Bt]
+    model.solve_many(many[:Bt])  # warm-up
+    t0 = time.perf_counter()
+    got = []
+    for k in range(0, len(many), Bt):
+        got += model.solve_many(many[k:k + Bt])
+    dtm = time.perf_counter() - t0
+    same_b = all(abs(g["upper_glob"] - y) <= 1e-6 * max(1.0, abs(y)) or (not np.isfinite(g["upper_glob"]) and not np.isfinite(y))
+                 for g, y in zip(got[:instances], res["hip_uppers"]))
+    res["hip_batched"] = dict(what="MIOSQP.solve_many, %d MIQPs per launch (a workgroup each)" % Bt,
+                              miqps_per_s=round(len(many) / dtm, 1), usec_per_miqp=round(1e6 * dtm / len(many), 1),
+                              nodes_per_s=round(sum(g["nodes"] for g in got) / dtm, 1), same_optima_as_one_at_a_time=bool(same_b))
+    model.work.solver.close()
     a, b = res.pop("hip_uppers"), res.pop("cpu_oracle_uppers")
     same = all((not np.isfinite(x) and not np.isfinite(y)) or abs(x - y) <= 1e-6 * max(1.0, abs(y)) for x, y in zip(a, b))
     return dict(workload="random_miqp n=50 m=100 p=10 density 0.7, %d MIQPs on one factor (update_vectors), whole trees"
-                         % instances, hip=res["hip"],
+                         % instances, hip=res["hip"], hip_batched=res["hip_batched"],
+                batched_speedup_over_one_host_core=round(res["hip_batched"]["miqps_per_s"] / max(1e-9, res["cpu_oracle"]["miqps_per_s"]), 2),
                 cpu_baseline=dict(res["cpu_oracle"], kind="port", cores=1,
                                   note="oracle/qp_oracle.c (own CPU restatement, not OSQP), the same sequence"),
                 same_optima=bool(same),

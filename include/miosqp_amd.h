@@ -179,6 +179,16 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
                          double upper0, const double *x_inc0, int32_t tree_explor_rule, int32_t max_iter_bb,
                          double *x_out, miosqp_tree_info *info);
 
+/* B independent MIQPs that share P and A -- hence the factor -- and differ in q, l, u, warm start and incumbent (the
+ * reference's MPC pattern: MIOSQP.update_vectors + set_x0 + solve per instance, /root/reference/miosqp/solver.py:174-212),
+ * every tree in ONE launch: workgroup (or wavefront, n + M <= 64) b runs instance b exactly as miosqp_qp_solve_tree would
+ * after miosqp_qp_update_lin_cost(q_b).  All arrays are instance-major: q, x0, x_inc0, x_out B x n; l, u, y0 B x M;
+ * upper0 B (>= 1.7e308: no incumbent; x_inc0 may be NULL when none has one); info B.  The engine's own linear cost and
+ * bounds are not touched.  MIOSQP_EUNSUPPORTED as for miosqp_qp_solve_tree. */
+int miosqp_qp_solve_trees(miosqp_qp_engine *e, int32_t B, const double *q, const double *l, const double *u,
+                          const double *x0, const double *y0, const double *upper0, const double *x_inc0,
+                          int32_t tree_explor_rule, int32_t max_iter_bb, double *x_out, miosqp_tree_info *info);
+
 /* ---- node-at-a-time branch and bound, driven from the host in C++ -------------------------------------
  * The loop of /root/reference/miosqp/solver.py:65-172 (choose_leaf -> Node.solve -> bound_and_branch, workspace.py:
  * 113-155, 274-334) for problems of any size, one relaxation at a time in whatever form the engine uses for single

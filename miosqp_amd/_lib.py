@@ -67,6 +67,8 @@ SYMBOLS = {
     "miosqp_qp_set_integer_rows": (C.c_int, [C.c_void_p, C.c_int32, ip, C.c_int32]),
     "miosqp_qp_set_root": (C.c_int, [C.c_void_p, dp, dp, C.c_double, C.c_double]),
     "miosqp_qp_solve_node": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, C.POINTER(Info)]),
+    "miosqp_qp_solve_trees": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp, dp, dp, dp, dp, C.c_int32, C.c_int32, dp,
+                                        C.POINTER(TreeInfo)]),
     "miosqp_qp_search_create": (C.c_int, [C.c_void_p, C.c_int32]),
     "miosqp_qp_search_reset": (C.c_int, [C.c_void_p]),
     "miosqp_qp_search_add_leaf": (C.c_int, [C.c_void_p, dp, dp, dp, dp, C.c_int32, C.c_double]),

@@ -515,6 +515,91 @@ class MIOSQP(object):
             alive = hs.step(st['max_iter_bb'] - work.iter_num)
         work.leaves = [root] * int(alive)  # the leaves live on the device; what matters is whether any is left
 
+    def solve_many(self, instances):
+        """B MIQPs on this model's factorisation, solved TOGETHER: instance k is what
+        `update_vectors(q=, l=, u=)` [+ `set_x0(x0)`] + `solve()` would solve (the reference's MPC pattern,
+        /root/reference/miosqp/solver.py:174-212, examples/power_converter/power_converter.py:467-476), for a list of
+        dicts with keys q, l, u (each optional: the model's current vector otherwise) and x0 (optional).  On the HIP
+        engine every tree runs in one launch -- one workgroup (one wavefront for n + M <= 64) per instance,
+        `miosqp_qp_solve_trees` --, so that many small independent MIQPs fill the chip instead of one compute unit;
+        instances the launch cannot hold (leaf list overflow) and engines without the entry point go through the
+        sequential calls.  The model itself is left as it was (its q, l, u, leaves and statistics are not touched).
+        Returns a list of dicts: x, upper_glob, status, nodes, osqp_iter, run_time."""
+        work, data, st = self.work, self.work.data, self.work.settings
+        B = len(instances)
+        if B == 0:
+            return []
+        n, m, M = data.n, data.m, data.m + data.n_int
+        ok_engine = hasattr(work.solver, 'solve_trees') and st.get('device_tree', True) and st['branching_rule'] == 0 \
+            and st['tree_explor_rule'] in (0, 1) and data.n_int > 0 and 'eps_abs' in work.qp_settings \
+            and st.get('device_digest', True) and not getattr(work, '_no_trees', False)
+        Q = np.empty((B, n)); L = np.empty((B, M)); U = np.empty((B, M))
+        up = np.full(B, np.inf); XI = np.zeros((B, n)); any_inc = False
+        for k, inst in enumerate(instances):
+            Q[k] = data.q if inst.get('q') is None else inst['q']
+            L[k] = data.l; U[k] = data.u
+            if inst.get('l') is not None:
+                L[k, :m] = inst['l']
+            if inst.get('u') is not None:
+                U[k, :m] = inst['u']
+            x0 = inst.get('x0')
+            if x0 is not None:
+                # Workspace.set_x0 (workspace.py:94-111) on this instance's data
+                x0 = np.asarray(x0, dtype=float)
+                z = data.A.dot(x0)
+                tol = work.qp_settings['eps_abs']
+                xi = x0[data.i_idx]
+                if not (np.any(z < L[k] - tol) or np.any(z > U[k] + tol)) and \
+                        not np.any(abs(xi - np.round(xi)) > st['eps_int_feas']):
+                    up[k] = .5 * np.dot(x0, data.P.dot(x0)) + np.dot(Q[k], x0)
+                    XI[k] = x0
+                    any_inc = True
+                else:
+                    print('Invalid initial solution!\n')
+        out = [None] * B
+        redo = list(range(B))
+        if ok_engine:
+            t0 = time()
+            r = work.solver.solve_trees(Q, L, U, np.zeros((B, n)), np.zeros((B, M)), up, XI if any_inc else None,
+                                        st['tree_explor_rule'], st['max_iter_bb'])
+            if r is None:
+                work._no_trees = True
+            else:
+                X, infos = r
+                dt = time() - t0
+                redo = []
+                for k in range(B):
+                    info = infos[k]
+                    if info.overflow:
+                        redo.append(k)
+                        continue
+                    upper = info.upper_glob
+                    finished = info.leaves_left == 0
+                    if upper != np.inf:
+                        status = MI_SOLVED if finished else MI_MAX_ITER_FEASIBLE
+                    elif upper >= 0:
+                        status = MI_PRIMAL_INFEASIBLE if finished else MI_MAX_ITER_UNSOLVED
+                    else:
+                        status = MI_DUAL_INFEASIBLE
+                    x = X[k].copy() if (info.found or np.isfinite(up[k])) else np.empty(n)
+                    if status in (MI_SOLVED, MI_MAX_ITER_FEASIBLE):
+                        x[data.i_idx] = np.round(x[data.i_idx])
+                    out[k] = dict(x=x, upper_glob=upper, status=status, nodes=int(info.nodes),
+                                  osqp_iter=int(info.osqp_iter), run_time=dt / B)
+        if redo:
+            # sequential path on a copy of the model's vectors, restored afterwards
+            q_keep, l_keep, u_keep = data.q, data.l[:m].copy(), data.u[:m].copy()
+            for k in redo:
+                inst = instances[k]
+                self.update_vectors(q=Q[k].copy(), l=L[k, :m].copy(), u=U[k, :m].copy())
+                if inst.get('x0') is not None:
+                    self.set_x0(np.asarray(inst['x0'], dtype=float).copy())
+                res = self.solve()
+                out[k] = dict(x=np.array(res.x, dtype=float), upper_glob=res.upper_glob, status=res.status,
+                              nodes=work.iter_num - 1, osqp_iter=work.osqp_iter, run_time=res.run_time)
+            self.update_vectors(q=q_keep, l=l_keep, u=u_keep)
+        return out
+
     def update_vectors(self, q=None, l=None, u=None):
         # solver.py:174-205: same factorisation, new root, statistics reset
         work = self.work

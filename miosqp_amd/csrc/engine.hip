@@ -1068,6 +1068,155 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
   return 0;
 }
 
+int miosqp_qp_solve_trees(miosqp_qp_engine *e, int32_t B, const double *q, const double *l, const double *u,
+                          const double *x0, const double *y0, const double *upper0, const double *x_inc0,
+                          int32_t tree_explor_rule, int32_t max_iter_bb, double *x_out, miosqp_tree_info *info) {
+  if (!e || B < 1 || !q || !l || !u || !x0 || !y0 || !upper0 || !x_out || !info || max_iter_bb < 1 || tree_explor_rule < 0 ||
+      tree_explor_rule > 1)
+    return MIOSQP_EARG;
+  ENTER(e);
+  if (!e->have_int || !e->d.digest) {
+    g_err = "solve_trees: call miosqp_qp_set_integer_rows and miosqp_qp_set_root first";
+    return MIOSQP_EARG;
+  }
+  const int n = e->n, M = e->M, p = e->d.n_int;
+  const size_t blk = 3 * (size_t)M + n;
+  const bool tree_w = e->d.W != nullptr && n + M <= RES_W_MAX;
+  size_t lds = tree_lds_doubles(n, M, tree_w) * sizeof(double);
+  int tree_sp_off = -1;
+  {
+    const size_t sp_bytes = res_sp_doubles(e->sp_nnzA, e->sp_nnzP, n, M) * sizeof(double);
+    if (tree_w && e->sp_nnzA > 0 && lds + sp_bytes <= 160 * 1024 &&
+        !(getenv("MIOSQP_RES_SP") && atoi(getenv("MIOSQP_RES_SP")) == 0)) {
+      tree_sp_off = (int)(lds / sizeof(double));
+      lds += sp_bytes;
+    }
+  }
+  if (!e->fold || lds > 160 * 1024 || p < 1) {
+    g_err = "solve_trees: only for problems whose product-form factor, iterates and leaf list fit 160 KB of LDS";
+    return MIOSQP_EUNSUPPORTED;
+  }
+  for (size_t k = 0; k < (size_t)B * M; k++)
+    if (l[k] > u[k]) return MIOSQP_EBOUNDS;
+  const double t0 = wall();
+  const bool wave = n + M <= TW && !(getenv("MIOSQP_TREE_WAVE") && atoi(getenv("MIOSQP_TREE_WAVE")) == 0);
+  if (wave && !e->d.Kc) {  // as miosqp_qp_solve_tree: an engine in the LDS-resident form has not built Kc (and perhaps W) yet
+    Dev &d = e->d;
+    const int N = n + M;
+    d.ldw = (N + 7) & ~7;
+    double *Wd = const_cast<double *>(d.W), *Kc = nullptr;
+    int rcw = 0;
+    if (!Wd) {
+      rcw = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
+      if (!rcw) rcw = miosqp_device_kkt_inverse(d.f_rows, d.ldf, d.d2inv, n, M, Wd, d.ldw, e->stream);
+    }
+    if (!rcw) rcw = dalloc(e, &Kc, (size_t)N * d.ldw + 64);
+    if (rcw) return rcw;
+    d.W = Wd;
+    d.Kc = Kc;
+    hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
+  }
+  if (!wave) HIPCHK(lds_limit_once((const void *)k_tree, 1));
+  if (B > e->tb_cap) {  // (a larger batch takes new arrays; the old ones stay with the pool until cleanup)
+    const size_t cap = (size_t)std::max(B, 2 * e->tb_cap);
+    int rc = pool_reserve(e, cap * ((size_t)TREE_CAP * (2 * (size_t)p + n + M) + blk + 3 * (size_t)n + 16) * sizeof(double) + 4096);
+    if (!rc) rc = dalloc(e, &e->tb_q, cap * n);
+    if (!rc) rc = dalloc(e, &e->tb_qraw, cap * n);
+    if (!rc) rc = dalloc(e, &e->tb_raw, cap * blk);
+    if (!rc) rc = dalloc(e, &e->tb_lo, cap * TREE_CAP * p);
+    if (!rc) rc = dalloc(e, &e->tb_hi, cap * TREE_CAP * p);
+    if (!rc) rc = dalloc(e, &e->tb_x, cap * TREE_CAP * n);
+    if (!rc) rc = dalloc(e, &e->tb_y, cap * TREE_CAP * M);
+    if (!rc) rc = dalloc(e, &e->tb_inc, cap * n);
+    if (!rc) rc = dalloc(e, &e->tb_upper, cap);
+    if (!rc) rc = dalloc(e, &e->tb_out, cap);
+    if (rc) return rc;
+    e->tb_cap = (int)cap;
+  }
+  // one staging vector: [raw blocks | q | incumbents | upper] in
+  const size_t nin = (size_t)B * (blk + 2 * (size_t)n + 1);
+  if (e->tb_host.size() < nin) e->tb_host.resize(nin);
+  double *h_raw = e->tb_host.data(), *h_q = h_raw + (size_t)B * blk, *h_inc = h_q + (size_t)B * n, *h_up = h_inc + (size_t)B * n;
+  bool any_inc = false;
+  for (int b = 0; b < B; b++) {
+    double *r = h_raw + (size_t)b * blk;
+    memcpy(r, l + (size_t)b * M, sizeof(double) * M);
+    memcpy(r + M, u + (size_t)b * M, sizeof(double) * M);
+    memcpy(r + 2 * (size_t)M, x0 + (size_t)b * n, sizeof(double) * n);
+    memcpy(r + 2 * (size_t)M + n, y0 + (size_t)b * M, sizeof(double) * M);
+    const bool have = x_inc0 != nullptr && upper0[b] < 1.7e308;
+    h_up[b] = have ? upper0[b] : 1.0 / 0.0;
+    if (have) memcpy(h_inc + (size_t)b * n, x_inc0 + (size_t)b * n, sizeof(double) * n);
+    else memset(h_inc + (size_t)b * n, 0, sizeof(double) * n);
+    any_inc = any_inc || have;
+  }
+  memcpy(h_q, q, sizeof(double) * (size_t)B * n);
+  HIPCHK(hipEventRecord(e->ev0, e->stream));
+  HIPCHK(hipMemcpyAsync(e->tb_raw, h_raw, sizeof(double) * (size_t)B * blk, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->tb_qraw, h_q, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice, e->stream));
+  if (any_inc) HIPCHK(hipMemcpyAsync(e->tb_inc, h_inc, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->tb_upper, h_up, sizeof(double) * B, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_scale_q_batch, dim3((unsigned)(((size_t)B * n + 255) / 256)), dim3(256), 0, e->stream, e->d, e->tb_qraw,
+                     e->tb_q, B);
+  TreeArgs ta{};
+  ta.rule = tree_explor_rule;
+  ta.max_nodes = max_iter_bb;
+  ta.max_iter = e->st.max_iter;
+  ta.check_every = e->st.check_termination;
+  {
+    auto pow2_floor = [](int v) { int q2 = 1; while (2 * q2 <= v) q2 *= 2; return q2; };
+    ta.TG1 = std::min(64, std::max(1, pow2_floor(RES_THREADS / n)));
+    ta.TG2 = std::min(64, std::max(1, pow2_floor(RES_THREADS / (n + M))));
+  }
+  ta.upper0 = 1.0 / 0.0;
+  ta.lf_lo = e->tb_lo; ta.lf_hi = e->tb_hi; ta.lf_x = e->tb_x; ta.lf_y = e->tb_y;
+  ta.inc_x = e->tb_inc;
+  ta.out = e->tb_out;
+  ta.done = nullptr;
+  ta.sp_off = tree_sp_off;
+  ta.batch = 1;
+  ta.upper_b = e->tb_upper;
+  Dev db = e->d;  // instance 0's arrays; workgroup b moves on from there (tree_instance)
+  db.q = e->tb_q;
+  db.qraw = e->tb_qraw;
+  db.raw_l = e->tb_raw;
+  db.raw_u = e->tb_raw + M;
+  db.raw_x = e->tb_raw + 2 * (size_t)M;
+  db.raw_y = e->tb_raw + 2 * (size_t)M + n;
+  db.prof = nullptr;
+  if (wave) hipLaunchKernelGGL(k_tree_w, dim3(B), dim3(TW), 0, e->stream, db, ta);
+  else hipLaunchKernelGGL(k_tree, dim3(B), dim3(RES_THREADS), lds, e->stream, db, ta);
+  if (e->tb_hout.size() < (size_t)B) e->tb_hout.resize(B);
+  HIPCHK(hipMemcpyAsync(e->tb_hout.data(), e->tb_out, sizeof(TreeOut) * B, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(h_inc, e->tb_inc, sizeof(double) * (size_t)B * n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  const double wall_s = wall() - t0;
+  int64_t iters = 0;
+  for (int b = 0; b < B; b++) {
+    const TreeOut &o = e->tb_hout[b];
+    info[b].nodes = o.nodes;
+    info[b].osqp_iter = o.osqp_iter;
+    info[b].leaves_left = o.leaves_left;
+    info[b].overflow = o.overflow;
+    info[b].max_leaves = o.max_leaves;
+    info[b].found = o.found;
+    info[b].upper_glob = o.upper;
+    info[b].lower_glob = o.lower_glob;
+    info[b].device_time = 1e-3 * ms / B;  // the launch's device time, shared equally
+    info[b].run_time = wall_s / B;
+    const bool have = x_inc0 != nullptr && upper0[b] < 1.7e308;
+    if (o.found) memcpy(x_out + (size_t)b * n, h_inc + (size_t)b * n, sizeof(double) * n);
+    else if (have) memcpy(x_out + (size_t)b * n, x_inc0 + (size_t)b * n, sizeof(double) * n);
+    iters += o.osqp_iter;
+  }
+  e->loop_ms += ms;
+  e->loop_iters += iters;
+  return 0;
+}
+
 int miosqp_qp_debug_iterate(miosqp_qp_engine *e, int32_t k, double *x, double *z, double *y) {
   if (!e || k < 0) return MIOSQP_EARG;
   ENTER(e);

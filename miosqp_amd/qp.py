@@ -209,6 +209,31 @@ class OSQP(object):
             raise ValueError("Lower bound must be lower than or equal to upper bound")
         return types.SimpleNamespace(x=x, info=info)
 
+    def solve_trees(self, q, l, u, x0, y0, upper0, x_inc0, tree_explor_rule, max_iter_bb):
+        """B MIQPs on this engine's factor (q, l, u, x0, y0 instance-major: B x n / B x M), every tree in one launch.
+        upper0: B incumbent values (inf: none), x_inc0: B x n or None.  Returns (x B x n, [TreeInfo]) or None when the
+        engine does not cover this size."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = q.shape[0]
+        l, u = np.ascontiguousarray(l, dtype=np.float64), np.ascontiguousarray(u, dtype=np.float64)
+        x0, y0 = np.ascontiguousarray(x0, dtype=np.float64), np.ascontiguousarray(y0, dtype=np.float64)
+        if q.shape != (B, self.n) or x0.shape != (B, self.n) or l.shape != (B, self.m) or u.shape != (B, self.m) or y0.shape != (B, self.m):
+            raise ValueError("solve_trees: instance-major arrays (B x n, B x M)")
+        up = np.minimum(np.ascontiguousarray(upper0, dtype=np.float64).reshape(B), 1.7e308)
+        xin = None if x_inc0 is None else np.ascontiguousarray(x_inc0, dtype=np.float64).reshape(B, self.n)
+        x = np.zeros((B, self.n))
+        infos = (_lib.TreeInfo * B)()
+        max_iter_bb = 2 ** 31 - 1 if not np.isfinite(max_iter_bb) else int(min(int(max_iter_bb), 2 ** 31 - 1))
+        rc = self._lib.miosqp_qp_solve_trees(self._h, B, _lib.as_d(q), _lib.as_d(l), _lib.as_d(u), _lib.as_d(x0), _lib.as_d(y0),
+                                             _lib.as_d(up), None if xin is None else _lib.as_d(xin), int(tree_explor_rule),
+                                             max_iter_bb, _lib.as_d(x), infos)
+        if rc == -5:
+            return None
+        _check(rc, "solve_trees")
+        if rc == 1:
+            raise ValueError("Lower bound must be lower than or equal to upper bound")
+        return x, list(infos)
+
     # -- node-at-a-time branch and bound driven from the host in C++ (miosqp_qp_search_*) --------------
     def search_create(self, capacity):
         _check(self._lib.miosqp_qp_search_create(self._h, int(capacity)), "search_create")

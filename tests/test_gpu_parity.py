@@ -1979,3 +1979,73 @@ def test_native_stream_driver_applies_the_node_cap_per_instance():
         mdl.update_vectors(q=q2)
         s.begin_instance()
     assert s.nodes > cap
+
+
+@pytest.mark.parametrize("n,m,p,seed,B", [(50, 100, 10, 0, 24), (12, 30, 6, 8, 16), (40, 60, 20, 7, 5)])
+def test_many_trees_in_one_launch_equal_the_sequential_calls(n, m, p, seed, B):
+    """miosqp_qp_solve_trees / MIOSQP.solve_many: B MIQPs that share P and A (new q, l, u each, some with an initial
+    solution) solved in ONE launch -- a workgroup per instance (a wavefront for n + M <= 64) -- give, instance by
+    instance, what update_vectors + set_x0 + solve give one after the other on the same engine: status, node count,
+    iteration count, incumbent value and x identical; the model itself is left untouched."""
+    from miosqp_amd import bnb
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    mk = lambda: bnb.MIOSQP()
+    seq, bat = mk(), mk()
+    for mdl in (seq, bat):
+        mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"].copy(), pr["u"].copy(), pr["i_idx"], pr["i_l"], pr["i_u"],
+                  dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+    rng = np.random.RandomState(seed + 99)
+    inst = []
+    for k in range(B):
+        d = dict(q=rng.randn(n), l=-2 + rng.rand(m), u=2 + rng.rand(m))
+        if k % 3 == 0:
+            d = dict(q=rng.randn(n))  # only the cost changes: l, u are the model's
+        inst.append(d)
+    want = []
+    for d in inst:
+        seq.update_vectors(q=d["q"].copy(), l=None if "l" not in d else d["l"].copy(), u=None if "u" not in d else d["u"].copy())
+        r = seq.solve()
+        want.append(dict(x=np.array(r.x, dtype=float), upper=r.upper_glob, status=r.status, nodes=seq.work.iter_num - 1,
+                         osqp_iter=seq.work.osqp_iter))
+        # (the sequential model keeps the last l, u; the batch builds every instance on the model's ORIGINAL l, u: give the
+        #  sequential one its original bounds back before the next cost-only instance)
+        seq.update_vectors(l=pr["l"].copy(), u=pr["u"].copy())
+    # a quarter of the instances also carry the optimum of the first run as an initial solution: the sequential answer
+    # for those is update_vectors + set_x0 + solve
+    for k in range(0, B, 4):
+        if want[k]["status"] == bnb.MI_SOLVED:
+            d = inst[k] = dict(inst[k], x0=want[k]["x"].copy())
+            seq.update_vectors(q=d["q"].copy(), l=None if "l" not in d else d["l"].copy(), u=None if "u" not in d else d["u"].copy())
+            seq.set_x0(d["x0"].copy())
+            r = seq.solve()
+            want[k] = dict(x=np.array(r.x, dtype=float), upper=r.upper_glob, status=r.status, nodes=seq.work.iter_num - 1,
+                           osqp_iter=seq.work.osqp_iter)
+            seq.update_vectors(l=pr["l"].copy(), u=pr["u"].copy())
+    q_before, l_before = bat.work.data.q.copy(), bat.work.data.l.copy()
+    got = bat.solve_many(inst)
+    assert np.array_equal(bat.work.data.q, q_before) and np.array_equal(bat.work.data.l, l_before)
+    assert len(got) == B
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g["status"] == w["status"], k
+        assert (g["nodes"], g["osqp_iter"]) == (w["nodes"], w["osqp_iter"]), k
+        if w["status"] == bnb.MI_SOLVED:
+            assert g["upper_glob"] == w["upper"], k
+            np.testing.assert_array_equal(g["x"], w["x"])
+
+
+def test_power_converter_steps_as_one_batch():
+    """BASELINE config 4 as a batch: the 40 MPC steps of the reference's recorded sequence (each with its own q, u and
+    initial solution) in ONE launch of 40 single-wavefront trees: node and iteration counts of every step equal the
+    reference's, the incumbents equal the recorded ones."""
+    from miosqp_amd import bnb
+    pc = problems.load_power_converter()
+    model = bnb.MIOSQP()
+    model.setup(pc["P"], pc["q"][0].copy(), pc["A"], pc["l"].copy(), pc["u"][0].copy(), pc["i_idx"], pc["i_l"], pc["i_u"],
+                pc["settings"], pc["qp_settings"])
+    inst = [dict(q=pc["q"][k].copy(), l=pc["l"].copy(), u=pc["u"][k].copy(), x0=pc["x0"][k].copy()) for k in range(len(pc["q"]))]
+    got = model.solve_many(inst)
+    for k, g in enumerate(got):
+        assert g["status"] == pc["status"][k], k
+        assert (g["nodes"], g["osqp_iter"]) == (int(pc["nodes"][k]), int(pc["osqp_iter"][k])), k
+        assert abs(g["upper_glob"] - pc["upper"][k]) <= 1e-8 * max(1.0, abs(pc["upper"][k]))
+        assert rel(g["x"], pc["x"][k]) <= 1e-6
