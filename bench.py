@@ -122,7 +122,7 @@ def large_leg(seed, device, nodes=12):
     cfg = problems.CONFIGS["cfg5"]
     prob = problems.random_miqp(seed=seed, **cfg)
     out = None
-    for pers in (-1, 0):
+    for pers in (-1, 1, 0):
         model, setup_s = setup_model(prob, dict(problems.QP_SETTINGS, device=device, pers=pers))
         eng = model.work.solver
         fs = eng.factor_stats()
@@ -136,7 +136,10 @@ def large_leg(seed, device, nodes=12):
                    moved_frac=round(fs["bytes_moved_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
                    setup_s=round(setup_s, 2))
         if fs["pers"]:
-            rec.update(factor_form="L, read from memory every iteration, ONE persistent launch per node (k_pers<false>)",
+            rec.update(factor_form=("sparse panels of L + the dense tail as S^-1 = L22^-T D22^-1 L22^-1 (the bytes of the two "
+                                    "triangles, one dense phase instead of two)" if fs["tail_inverse"] else
+                                    "L (sparse panels + the two triangular sweeps of the pre-inverted tail)") +
+                                   ", read from memory every iteration, ONE persistent launch per node (k_pers<false>)",
                        kernel="k_pers<false>", launches=r["launches"],
                        iterations_per_launch=round(r["loop_iters"] / max(1, r["launches"]), 1),
                        usec_per_launch=round(1e3 * r["loop_ms"] / max(1, r["launches"]), 1))
@@ -162,6 +165,8 @@ def large_leg(seed, device, nodes=12):
             if not fs["pers"]:
                 eng.close()
                 break
+        elif fs["pers"]:
+            out["triangular_sweeps_form"] = rec
         else:
             out["four_launch_form"] = rec
         eng.close()
@@ -408,7 +413,7 @@ def main():
     ap.add_argument("--python-loop", action="store_true",
                     help="headline: drive every node from Python (solve_node + bnb.Workspace, vectors over PCIe) instead "
                          "of the C++ host loop on device-resident leaves (miosqp_qp_search_*)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg5"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg5", "cfg5x"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -752,7 +757,8 @@ def main():
         elif fs["pers"]:  # likewise one launch per node
             launches = max(1, nodes_here)
             us, by = 1e3 * loop_ms / launches, fs["bytes_per_iter"] * loop_iters / launches
-            kern.append(dict(kernel="k_pers", usec=round(us, 3), bytes=round(by), gbs=round(by / max(us, 1e-9) * 1e-3, 1),
+            kern.append(dict(kernel="k_pers_small" if fs["pers_small"] else "k_pers", usec=round(us, 3), bytes=round(by),
+                             gbs=round(by / max(us, 1e-9) * 1e-3, 1), bytes_moved=round(fs["bytes_moved_per_iter"] * loop_iters / launches),
                              launches=launches, iterations_per_launch=round(loop_iters / launches, 1)))
             it_us, it_bytes = (0.0, 0.0) if args.no_probes else eng.time_kernel(4, 200)
         else:

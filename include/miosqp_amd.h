@@ -76,7 +76,9 @@ typedef struct miosqp_qp_settings {
                                 iteration; the kernel boundaries of the multi-kernel forms become tagged exchanges
                                 between co-resident workgroups.  Any size that fits one workgroup's LDS operand
                                 buffers (n+M <= ~17 000 in product form, n <= ~9 000 in factor form); auto: problems
-                                beyond the cooperative solver's n+M <= 2048 */
+                                beyond the cooperative solver's n+M <= 2048.  2 (factor form): the dense tail as the
+                                explicit inverse of the reduced Hessian, S^-1 = L22^-T D22^-1 L22^-1 -- the bytes of the
+                                two triangles, ONE dense phase per iteration instead of two */
   int32_t reserved[1];
 } miosqp_qp_settings;
 

@@ -16,6 +16,9 @@ CONFIGS = {
     "cfg1": dict(n=50, m=100, p=10, density=0.7),
     "cfg2": dict(n=500, m=1000, p=250, density=0.7),
     "cfg5": dict(n=5000, m=10000, p=2500, density=0.01),
+    # not a BASELINE config: config 5's shape scaled until the factor's dense tail (2 x 512 MB per iteration) no longer
+    # fits the 256 MiB Infinity Cache -- the data point that shows HBM, not the cache, delivering the stream
+    "cfg5x": dict(n=8000, m=16000, p=4000, density=0.01),
 }
 
 # settings dicts of the reference benchmark (run_example.py:98-116)

@@ -479,7 +479,7 @@ def test_batched_search_finds_the_same_optimum():
 
 
 # (fold, resident, coop, pers)
-FORMS = [(0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0), (1, 0, 1, 0), (0, 0, 0, 1), (1, 0, 0, 1)]
+FORMS = [(0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0), (1, 0, 1, 0), (0, 0, 0, 1), (1, 0, 0, 1), (0, 0, 0, 2)]
 
 
 @pytest.mark.parametrize("fold,resident,coop,pers", FORMS)
@@ -487,7 +487,8 @@ def test_both_factor_forms_match_oracle(oracle_mod, fold, resident, coop, pers):
     """fold=0: factor form L (4 kernels per iteration); fold=1: product form L^-1 (2 kernels);
     resident=1: the whole solve in one LDS-resident workgroup; coop=1: the whole solve in one
     cooperative launch, explicit KKT inverse in registers, one exchange per iteration; pers=1: the whole solve
-    in one persistent launch that streams the factor (either form) from memory in every iteration."""
+    in one persistent launch that streams the factor (either form) from memory in every iteration; pers=2: the same in
+    factor form with the dense tail as the explicit inverse of the reduced Hessian (one dense phase instead of two)."""
     from miosqp_amd import qp
     pr = problems.random_miqp(60, 120, 30, seed=11)
     A, l, u = problems.extended(pr)
@@ -984,7 +985,7 @@ def test_persistent_solver_random_sweep(oracle_mod):
                     l[j], u[j] = u[j], l[j]
         fold = int(rng.randint(0, 2))
         g, o = qp.OSQP(), oracle_mod.OSQP()
-        g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=0, coop=0, pers=1, **problems.QP_SETTINGS)
+        g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=0, coop=0, pers=1 + int(rng.randint(0, 2)), **problems.QP_SETTINGS)
         o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
         fs = g.factor_stats()
         assert fs["pers"] is True, (trial, n, m, p)
@@ -1137,6 +1138,7 @@ def test_persistent_kernels_agree_and_take_sizes_beyond_the_cooperative_grid(ora
         g.setup(pr["P"], pr["q"], A, l, u, fold=fold, **problems.QP_SETTINGS)
         fs = g.factor_stats()
         assert fs["pers"] is True and fs["coop"] is False and fs["fold"] == bool(fold)
+        assert fs["tail_inverse"] == (not fold)  # the factor form's automatic choice: its dense tail as S^-1
         for k in (1, 10, 40):
             g.warm_start(x=xw, y=yw)
             o.warm_start(x=xw, y=yw)

@@ -11,12 +11,15 @@ from oracle import oracle
 def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
 
+PERS = int(os.environ.get("PERS_MODE", "1"))
+
+
 def one(n, m, p, dens, seed, fold, check_oracle=True, reps=300):
     pr = problems.random_miqp(n, m, p, density=dens, seed=seed)
     A, l, u = problems.extended(pr)
     M = A.shape[0]
     t0 = time.time()
-    g = qp.OSQP(); g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=0, coop=0, pers=1, **problems.QP_SETTINGS)
+    g = qp.OSQP(); g.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=0, coop=0, pers=PERS, **problems.QP_SETTINGS)
     fs = g.factor_stats()
     print("n=%d m=%d p=%d dens=%g fold=%d: pers=%s setup %.2fs" % (n, m, p, dens, fold, fs["pers"], time.time() - t0), flush=True)
     if not fs["pers"]:
@@ -45,7 +48,7 @@ def one(n, m, p, dens, seed, fold, check_oracle=True, reps=300):
     print("  multi-kernel form : %.2f us / iteration" % us2, flush=True)
     for name, eng in (("persistent", None), ("multi-kernel", g2)):
         if eng is None:
-            eng = qp.OSQP(); eng.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=0, coop=0, pers=1, **problems.QP_SETTINGS)
+            eng = qp.OSQP(); eng.setup(pr["P"], pr["q"], A, l, u, fold=fold, resident=0, coop=0, pers=PERS, **problems.QP_SETTINGS)
         best = None
         for rep in range(3):
             eng.warm_start(x=np.zeros(n), y=np.zeros(M))
