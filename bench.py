@@ -669,16 +669,27 @@ def main():
             ss = sh.ss
             stepper, restart = sh.step, sh.begin_instance
 
+        class _StreamCount(object):  # what next_instance() reads: nodes of the tree that just closed, over all ranks
+            base = 0
+            global_nodes = property(lambda self: (sh.global_nodes if sh is not None else ss.nodes - self.base))
+
+            def begin_instance(self):
+                self.base = ss.nodes
+
+        sc = _StreamCount()
+        sc.base = ss.nodes
+
         def stream_steps(count):
             for _ in range(count):
                 if stepper() == 0:
-                    next_instance()
+                    next_instance(sc)
                     restart()
 
         stream_steps(args.stream_warmup)
         sync()
         eng.batch_stats(reset=True)
         n2, i2, c2 = ss.nodes, ss.iters, ss.chunks
+        del stream["closed"][:]
         t2 = time.perf_counter()
         stream_steps(args.stream_chunks)
         eng.pool_collect(0)  # the launch in flight belongs to the timed region (its digests are not counted)
@@ -702,6 +713,20 @@ def main():
                        end_to_end_over_device=round(1e-3 * (float(tots[2]) / world) / dts, 3),
                        open_leaves=len(ss.open), pool_slots_free=len(ss.free), dropped_at_refill=ss.dropped,
                        waves=waves)
+        closed_s = list(stream["closed"])
+        bt = dict(closed_in_timed_region=len(closed_s))
+        if len(closed_s) >= 2:
+            gaps = [closed_s[k][0] - closed_s[k - 1][0] for k in range(1, len(closed_s))]
+            bt.update(mean_ms_to_close=round(1e3 * float(np.mean(gaps)), 3),
+                      mean_nodes_per_tree=round(float(np.mean([c[1] for c in closed_s[1:]])), 1),
+                      trees_per_s=round(1.0 / float(np.mean(gaps)), 2))
+            if trees.get("mean_nodes_per_tree"):
+                # nodes the stream spends per closed tree over what the node-at-a-time search of `value` spends (other
+                # instances of the same stream of MIQPs; with one rank that search is the sequential one)
+                bt["node_ratio_vs_headline"] = round(bt["mean_nodes_per_tree"] / trees["mean_nodes_per_tree"], 2)
+        batched["trees"] = bt
+        batched["note"] = ("the compiled stream driver pushes as many leaves per round as the launch in flight has freed when "
+                           "it looks: node counts (not results) vary from run to run") if native else None
         if sh is not None:
             batched["leaves_moved_rank0"] = sh.moved
         # the same tree on TWO pools of this GPU (stream.MultiPoolSearch: two engines, two host threads): the sweeps

@@ -36,7 +36,10 @@ def test_roofline_and_cpu_baseline_objects():
     # register-resident solver (its `achieved` is algorithmic bytes over time; `hbm_measured_gbs` is what HBM delivered)
     assert r["bound"] in ("hbm", "exchange-latency") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     if r["bound"] == "exchange-latency":
-        assert r["kernel"] == "k_coop" and r["traffic_source"] and "committed profile" in r["traffic_source"]
+        # the counter traffic comes from a committed PMC summary OF THE SAME DEVICE CODE (source digest), or not at all
+        assert r["kernel"] == "k_coop" and r["traffic_source"]
+        assert ("committed profile" in r["traffic_source"]) == (r["traffic"] is not None)
+        assert r["traffic"] is not None or "other device code" in r["traffic_source"]
         assert r["hbm_measured_gbs"] is None or r["hbm_measured_gbs"] < 0.2 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
     assert r["traffic"] is None or r["traffic"] > 0
@@ -87,6 +90,60 @@ def test_every_roofline_fraction_can_be_recomputed_from_profiles():
     pmc = json.load(open(nodes[-1].replace("_bench_nodes_only.json", "_pmc_traffic.json")))["kernels"]
     tr = [v for kk, v in pmc.items() if kk.startswith("k_coop")][0]["traffic_bytes"]
     assert tr < 0.1 * k["bytes"]  # register-resident factor: HBM moves a few percent of the algorithmic bytes
-    c5 = json.load(open(nodes[-1].replace("_bench_nodes_only.json", "_pmc_traffic_cfg5.json")))["kernels"]
+    four = nodes[-1].replace("_bench_nodes_only.json", "_pmc_traffic_cfg5_four_launches.json")
+    c5 = json.load(open(four if os.path.exists(four) else nodes[-1].replace("_bench_nodes_only.json", "_pmc_traffic_cfg5.json")))["kernels"]
     tail = [v for kk, v in c5.items() if kk.startswith("k_tail_fwd")][0]
     assert tail["early_exit_dispatches"] > 0 and 0.9e8 <= tail["traffic_bytes"] <= 1.2e8  # 12.5 M entries x 8 B
+
+
+def _table_avg_us(table, prefix):
+    rows = [ln.replace("[early exit]", "").split() for ln in open(table) if prefix in ln and not ln.startswith("#")]
+    calls = sum(int(r[-6]) for r in rows)
+    return sum(float(r[-5]) for r in rows) / calls * 1e-3, calls
+
+
+def test_streaming_form_fractions_can_be_recomputed_from_profiles():
+    """the `stream` and `config5` fractions, like k_coop's, follow from files under profiles/ alone --
+    the node-only run of each form (JSON, untraced + traced), the rocprofv3 kernel table of the traced run and the PMC
+    summary of the same command.  A single-launch kernel is one dispatch per node, so tracing does not distort it (the
+    two-launch form is: see the traced / untraced pair of that form)."""
+    P = os.path.join(ROOT, "profiles")
+    base = sorted(glob.glob(os.path.join(P, "r*_bench_persistent_untraced.json")))
+    if not base:
+        return  # rounds before the persistent solver
+    tag = os.path.basename(base[-1]).split("_")[0]
+
+    def load(name):
+        return json.load(open(os.path.join(P, "%s_%s" % (tag, name))))
+
+    # ---- config 2, product form, one persistent launch per node
+    u, t = load("bench_persistent_untraced.json"), load("bench_persistent.json")
+    k = u["roofline"]["kernels"][0]
+    assert k["kernel"] == "k_pers_small"
+    assert abs(k["bytes"] - u["roofline"]["iteration"]["bytes"] * k["iterations_per_launch"]) <= 1e-3 * k["bytes"]
+    assert abs(u["roofline"]["frac"] - k["bytes"] / k["usec"] * 1e-3 / 8000.0) <= 2e-3
+    avg_us, calls = _table_avg_us(os.path.join(P, tag + "_rocprofv3_kernel_stats_persistent.txt"), "k_pers_small")
+    kt = t["roofline"]["kernels"][0]
+    assert calls >= kt["launches"]
+    assert abs(avg_us - kt["usec"]) <= 0.15 * kt["usec"]            # the table also holds the warm-up nodes
+    assert abs(kt["usec"] - k["usec"]) <= 0.05 * k["usec"]          # traced == untraced for a one-launch-per-node kernel
+    pmc = [v for kk, v in load("pmc_traffic_persistent.json")["kernels"].items() if kk.startswith("k_pers_small")][0]
+    assert pmc["traffic_bytes"] < 0.2 * k["bytes"]                  # the factor streams from L2 at this size, not from HBM
+    # the two-launch form of the same nodes: tracing more than doubles its wall time per iteration
+    u2, t2 = load("bench_two_kernel_form_untraced.json"), load("bench_two_kernel_form.json")
+    assert t2["roofline"]["iteration"]["usec_in_timed_region"] > 1.5 * u2["roofline"]["iteration"]["usec_in_timed_region"]
+    assert u["roofline"]["frac"] > u2["roofline"]["frac"]
+    # ---- config 5 and the size beyond the Infinity Cache, factor form, one persistent launch per node
+    for name, beyond in (("cfg5", False), ("cfg5x", True)):
+        u = load("bench_%s_untraced.json" % name)
+        k = u["roofline"]["kernels"][0]
+        assert k["kernel"] == "k_pers"
+        assert abs(u["roofline"]["frac"] - k["bytes"] / k["usec"] * 1e-3 / 8000.0) <= 2e-3
+        avg_us, calls = _table_avg_us(os.path.join(P, "%s_rocprofv3_kernel_stats_%s.txt" % (tag, name)), "k_pers<false>")
+        assert calls >= k["launches"] and 0.8 * k["usec"] <= avg_us <= 1.5 * k["usec"]
+        pmc = [v for kk, v in load("pmc_traffic_%s.json" % name)["kernels"].items() if kk.startswith("k_pers<false>")][0]
+        per_iter = pmc["traffic_bytes"] / k["iterations_per_launch"]   # (mean over the launches, warm-up included: +-20 %)
+        moved = k["bytes_moved"] / k["iterations_per_launch"]
+        assert 0.8 * moved <= per_iter <= 1.6 * moved, (name, per_iter, moved)
+        if beyond:
+            assert moved > 2 * 256 * 2 ** 20  # two Infinity Caches' worth per iteration: the counters count HBM here

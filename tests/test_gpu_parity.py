@@ -1445,6 +1445,34 @@ def test_two_ranks_stream_on_one_device(tmp_path):
     assert bt["nodes"] > 0 and bt["node_iters_per_s"] > 0 and 0 < bt["column_occupancy"] <= 1.0
 
 
+def test_two_ranks_hosted_search_on_one_device(tmp_path):
+    """The bench's headline form with more than one rank -- dist.ShardedStream over search.HostedSearch: every rank runs
+    the compiled node-at-a-time loop on its share of the tree, incumbent all-gather + broadcast and dry-rank feed after
+    every step -- as two processes time-sharing GPU 0 (gloo): both ranks end with the optimum of the sequential search
+    on the same engine form (value to 1e-9, integer part exactly), status Solved, and together they visited at least
+    the sequential search's nodes."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = str(tmp_path / "rec")
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(root, "tests", "dist_worker_gpu.py"), out, "60", "120", "30", "3"],
+                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert tr.returncode == 0, tr.stderr[-3000:]
+    recs = [json.load(open("%s.%d" % (out, r))) for r in (0, 1)]
+    r0 = recs[0]
+    assert r0["seq_status"] == "Solved"
+    ii = problems.random_miqp(60, 120, 30, seed=3)["i_idx"]
+    for r in recs:
+        assert r["status"] == "Solved"
+        assert abs(r["upper"] - r0["seq_upper"]) <= 1e-9 * max(1.0, abs(r0["seq_upper"]))
+        np.testing.assert_array_equal(np.array(r["x"])[ii], np.array(r0["seq_x"])[ii])
+    assert recs[0]["local_nodes"] > 0 and recs[1]["local_nodes"] > 0  # both ranks worked
+    assert r0["nodes_total"] >= r0["seq_nodes"]
+
+
 @pytest.mark.parametrize("n,m,p,seed,rule", [(30, 150, 15, 4, 1), (50, 100, 25, 2, 1), (20, 40, 10, 1, 0), (100, 150, 40, 7, 1),
                                               (60, 120, 60, 3, 0)])
 def test_hosted_search_equals_the_python_loop(n, m, p, seed, rule):

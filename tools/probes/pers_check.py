@@ -70,5 +70,7 @@ elif mode == "cfg2":
 elif mode == "big":
     one(1000, 2000, 500, 0.7, 0, 1, check_oracle=False)
     one(1500, 3000, 750, 0.5, 0, 1, check_oracle=False)
+elif mode == "cfg5x":
+    one(8000, 16000, 4000, 0.01, 0, 0, check_oracle=False, reps=50)
 elif mode == "cfg5":
     one(5000, 10000, 2500, 0.01, 0, 0, check_oracle=False, reps=100)
