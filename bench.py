@@ -607,6 +607,22 @@ def main():
                      mean_nodes_per_tree=round(float(np.mean([c[1] for c in closed[1:]])), 1),
                      trees_per_s=round(1.0 / float(np.mean(gaps)), 2))
 
+    # A driver-sized run (--steps 20 .. 150) ends before the first tree of the timed region closes (seed 0: ~220 nodes):
+    # one more tree, from its root to the end, timed on its own -- what branch and bound buys, next to the rates
+    if hosted and world == 1 and len(closed) < 2:
+        next_instance(head)
+        torch.cuda.synchronize()
+        tn0, ti0 = head.hs.nodes, head.hs.iters
+        tt0 = time.perf_counter()
+        while head.hs.step(10 ** 6) != 0:
+            pass
+        torch.cuda.synchronize()
+        tdt = time.perf_counter() - tt0
+        trees["one_tree_after_the_timed_region"] = dict(ms_to_close=round(1e3 * tdt, 3), nodes=head.hs.nodes - tn0,
+                                                       iters=head.hs.iters - ti0,
+                                                       upper_glob=float(model.work.upper_glob))
+        next_instance(head)
+
     # ---- extra leg: the same node-at-a-time workload with the reference's own control flow -- bnb.Workspace in
     #      Python driving miosqp_qp_solve_node, vectors over PCIe per node -- next to the hosted loop of `value`
     pyloop = None
