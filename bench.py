@@ -751,7 +751,8 @@ def main():
             rngs = [np.random.RandomState(args.seed + 777) for _ in range(args.pools)]
 
             def make_model():
-                return setup_model(prob, dict(qs), backend=None)[0]
+                # (the one-launch-per-chunk sweeps need the whole chip to themselves: two pools take the launches)
+                return setup_model(prob, dict(qs, batch_pers=0), backend=None)[0]
 
             def reroot(k, mdl):
                 r = rngs[k]  # every pool draws the same numbers

@@ -79,7 +79,11 @@ typedef struct miosqp_qp_settings {
                                 beyond the cooperative solver's n+M <= 2048.  2 (factor form): the dense tail as the
                                 explicit inverse of the reduced Hessian, S^-1 = L22^-T D22^-1 L22^-1 -- the bytes of the
                                 two triangles, ONE dense phase per iteration instead of two */
-  int32_t reserved[1];
+  int32_t batch_pers;        /* -1 auto, 0 off, 1 on: batched mode (solve_batch, the leaf pool's stream) runs the lock-step
+                                iterations of a chunk as ONE persistent launch with the product-form factor held in the
+                                registers and LDS of 256 co-resident workgroups (n <= 512, rows in the products <= 1024;
+                                auto: n >= 256).  Called off -- the chunk goes through two launches per iteration
+                                instead -- when the device is shared and the workgroups are not co-resident in time */
 } miosqp_qp_settings;
 
 /* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus

@@ -18,8 +18,7 @@ class Settings(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf", "eps_dual_inf")] + \
                [(k, C.c_int32) for k in ("max_iter", "scaling", "check_termination", "warm_start",
-                                         "device", "max_batch", "fold", "resident", "setup_on_device", "coop", "pers")] + \
-               [("reserved", C.c_int32 * 1)]
+                                         "device", "max_batch", "fold", "resident", "setup_on_device", "coop", "pers", "batch_pers")]
 
 
 class Info(C.Structure):

@@ -189,6 +189,7 @@ struct Dev {
 #include "kernels_resident.inc"  // LDS-resident single-workgroup solver (k_resident)
 #include "kernels_node.inc"  // per-solve prologue / epilogue kernels (scaling, warm start, finish, node digest, objective)
 #include "kernels_batched.inc"  // batched mode: sparse row kernels, dense vector-FMA tiles, fp64 matrix-core tiles, batched test
+#include "kernels_bpers.inc"  // batched mode: a chunk's lock-step iterations as one persistent launch, the factor in registers and LDS (kbp)
 #include "kernels_tree.inc"  // a whole branch-and-bound tree in one launch (LDS-resident problems)
 #include "kernels_pool.inc"  // device-resident leaf pool, streaming batch (refill / harvest between chunks)
 #include "host.inc"  // host side: engine object, allocation, launches, graph capture, solve loops
@@ -203,7 +204,7 @@ namespace {
 // the dynamic-LDS ceiling of a kernel is a property of (process, device, kernel): raised to the chip's 160 KB once instead of
 // at every set-up (the call costs ~40 us, a fifth of a small problem's set-up)
 hipError_t lds_limit_once(const void *fn, int which) {
-  static bool done[5][64] = {};
+  static bool done[9][64] = {};
   int dev = 0;
   hipError_t rc = hipGetDevice(&dev);
   if (rc != hipSuccess) return rc;
@@ -239,6 +240,7 @@ int miosqp_qp_default_settings(miosqp_qp_settings *s) {
   s->setup_on_device = -1;
   s->coop = -1;
   s->pers = -1;
+  s->batch_pers = -1;
   return 0;
 }
 
@@ -260,7 +262,19 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->x_tail) hipGraphExecDestroy(e->x_tail);
   if (e->g_full) hipGraphDestroy(e->g_full);
   if (e->g_tail) hipGraphDestroy(e->g_tail);
-  for (void *p : e->allocs) hipFree(p);
+  for (void *p : e->allocs) {
+    bool parked = false;
+    for (const ParkedChunk &c : e->chunks)
+      if (c.p == p && c.bytes <= CHUNK_PARK_MAX && !getenv("MIOSQP_NO_CACHE")) {
+        std::lock_guard<std::mutex> lk(g_rt_mutex);
+        if (g_chunk_cache.size() < 8) {
+          g_chunk_cache.push_back(c);
+          parked = true;
+        }
+        break;
+      }
+    if (!parked) hipFree(p);
+  }
   drop_stream_graph(e);
   for (hipEvent_t ev : e->ev_pool)
     if (ev) hipEventDestroy(ev);
@@ -270,7 +284,6 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
     if (S->dg) hipHostFree(S->dg);
     delete S;
   }
-  if (e->h_tree) hipHostFree(e->h_tree);
   if (e->h_ready) hipHostFree(e->h_ready);
   if (e->h_dg) hipHostFree(e->h_dg);
   if (e->h_pctl) hipHostFree(e->h_pctl);
@@ -783,7 +796,7 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
       HIPCHK(hipMemcpy(ai, aint.data(), sizeof(double) * n, hipMemcpyHostToDevice));
       hipLaunchKernelGGL(k_drop_bound_columns, dim3((ld2 + 255) / 256, n), dim3(256), 0, e->stream, e->d.f_rows, e->d.ldf,
                          f2, ld2, m, n_int, n);
-      HIPCHK(hipStreamSynchronize(e->stream));
+      // (no wait: every reader of f2 is a later kernel on this stream)
       e->d.f_rows2 = f2;
       e->d.ldf2 = ld2;
       e->d.a_int = ai;
@@ -967,8 +980,16 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     // The one-wavefront search reads the root straight from the pinned staging block and writes incumbent and
     // outcome into coherent host memory, the completion word last: ONE launch and no copy per MIQP (three copies and
     // two events around a 60-400 us kernel were 25 us).  Device time: the kernel's own 100 MHz stamps.
-    if (!e->h_tree) {
-      HIPCHK(hipHostMalloc((void **)&e->h_tree, sizeof(double) * ((size_t)n + 16), hipHostMallocCoherent));
+    if (!e->h_tree) {  // lives in the runtime bundle: a pinned allocation per engine was ~80 us of a 130 us first solve
+      if (e->rt.tree_cap < (size_t)n + 16) {
+        if (e->rt.h_tree) hipHostFree(e->rt.h_tree);
+        e->rt.h_tree = nullptr;
+        e->rt.tree_cap = 0;
+        const size_t cap = std::max<size_t>(512, (size_t)n + 16);
+        HIPCHK(hipHostMalloc((void **)&e->rt.h_tree, sizeof(double) * cap, hipHostMallocCoherent));
+        e->rt.tree_cap = cap;
+      }
+      e->h_tree = e->rt.h_tree;
       memset(e->h_tree, 0, sizeof(double) * ((size_t)n + 16));
     }
     unsigned long long *done = e->h_tree;
@@ -1294,7 +1315,7 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[3] = (int64_t)b[4];
   out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0) |
            (e->pers ? 16 : 0) | ((e->pers && e->pp.sinv) ? 32 : 0) | ((e->pers && e->pp.small) ? 64 : 0) |
-           ((e->d.coop_nap & 0xff) << 8);
+           ((e->d.coop_nap & 0xff) << 8) | (e->kbp ? (1 << 16) : 0);
   return 0;
 }
 
@@ -1312,14 +1333,18 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 // debug: per-block (start, end) wall-clock stamps (100 MHz) of ONE launch of a product-form kernel
 int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
                              int32_t *nblocks) {
-  if (!e || !out || which < 0 || which > 4 || (which < 4 && !e->fold) || (which == 2 && !e->coop) || (which == 3 && e->Bcap == 0) ||
-      (which == 4 && !e->pers))
+  if (!e || !out || which < 0 || which > 5 || (which < 4 && !e->fold) || (which == 2 && !e->coop) || (which == 3 && e->Bcap == 0) ||
+      (which == 4 && !e->pers) || (which == 5 && !e->kbp))
     return MIOSQP_EARG;
   ENTER(e);
   unsigned long long *buf = nullptr;
   HIPCHK(hipMalloc((void **)&buf, sizeof(unsigned long long) * 2 * 8192));
   HIPCHK(hipMemsetAsync(buf, 0, sizeof(unsigned long long) * 2 * 8192, e->stream));
-  if (which == 4) {
+  if (which == 5) {
+    // every column live for the measurement (the columns of a finished wave are all decided); the caller solves anew
+    HIPCHK(hipMemsetAsync(e->d.c_done, 0, sizeof(int) * e->d.Bs, e->stream));
+    launch_kbp(e, e->d, e->Bcap / 64, 5);
+  } else if (which == 4) {
     launch_pers(e, 20, 0, 0);
   } else if (which == 3) {
     for (int i = 0; i < 5; i++) launch_iteration_b(e, e->Bcap / 64);
@@ -1335,7 +1360,10 @@ int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, 
   // which == 4: 1000 iterations of the persistent streaming solver, tests every 25; per workgroup 16 words: shader
   // clocks of thread 0 in {sparse forward, forward wait, forward rows, forward epilogue, backward wait, backward rows,
   // backward epilogue (+ sparse backward), tests}, iterations
-  if (which == 4) launch_pers(e, 1000, 25, 0);
+  // which == 5: 100 lock-step iterations of kbp at full width; per workgroup 16 words: shader clocks of thread 0 in
+  // {forward sweep, forward reduce + store, barrier, x sweep, x reduce + epilogue, constraint tiles, barrier}, iterations
+  if (which == 5) launch_kbp(e, e->d, e->Bcap / 64, 100, true);
+  else if (which == 4) launch_pers(e, 1000, 25, 0);
   else if (which == 3) launch_bd(e, e->Bcap / 64, 0);
   else if (which == 2) launch_coop(e, 1000, 25, 0);
   else if (which == 0) launch_fold_fwd(e); else launch_fold_bwd(e);
@@ -1363,7 +1391,7 @@ int miosqp_qp_debug_clock(miosqp_qp_engine *e, double *cycles, double *ticks) {
 // debug counters: 0 = wave compactions performed by solve_batch so far
 int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which) {
   if (!e) return -1;
-  return which == 0 ? e->compactions : -1;
+  return which == 0 ? e->compactions : which == 1 ? e->kbp_fallbacks : -1;
 }
 
 int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters, int64_t *node_iters,

@@ -396,7 +396,8 @@ class OSQP(object):
         return dict(nnz_L=int(out[0]), nnz_panel=int(out[1]), tail_order=int(out[2]),
                     bytes_per_iter=int(out[3]), bytes_moved_per_iter=int(out[8]), coop_fallbacks=int(out[9]),
                     tpr=(int(out[4]), int(out[5]), int(out[6])),
-                    fold=bool(out[7] & 1), resident=bool(out[7] & 2), setup_on_device=bool(out[7] & 4), coop=bool(out[7] & 8), pers=bool(out[7] & 16), tail_inverse=bool(out[7] & 32), pers_small=bool(out[7] & 64), coop_nap=(out[7] >> 8) & 0xff)
+                    fold=bool(out[7] & 1), resident=bool(out[7] & 2), setup_on_device=bool(out[7] & 4), coop=bool(out[7] & 8), pers=bool(out[7] & 16), tail_inverse=bool(out[7] & 32), pers_small=bool(out[7] & 64), coop_nap=(out[7] >> 8) & 0xff,
+                    batch_pers=bool(out[7] & (1 << 16)))
 
     def loop_stats(self, reset=False):
         ms, it = C.c_double(), C.c_int64()
@@ -412,6 +413,10 @@ class OSQP(object):
 
     def compactions(self):
         return int(self._lib.miosqp_qp_debug_counter(self._h, 0))
+
+    def batch_pers_fallbacks(self):
+        """Times a chunk's persistent launch (kbp) was called off and the engine went back to the launches."""
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 1))
 
     def time_kernel(self, which, reps=200):
         us, by = C.c_double(), C.c_double()

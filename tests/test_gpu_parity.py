@@ -456,6 +456,56 @@ def test_config3_full_size_wave_of_256_leaves(oracle_mod):
     _check_wave(g2, o, pr, A, l, u, kids, 28, True)             # 16 more against the oracle
 
 
+def _cfg3_engine(pr, A, l, u, width, batch_pers):
+    from miosqp_amd import qp
+    g = qp.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **dict(problems.QP_SETTINGS, max_batch=width, batch_pers=batch_pers))
+    g.set_integer_rows(pr["i_idx"], pr["A"].shape[0])
+    g.set_root(l, u, 1e-3, 1e-3)
+    return g
+
+
+def _same_wave(a, b):
+    np.testing.assert_array_equal(a.status_val, b.status_val)
+    np.testing.assert_array_equal(a.iter, b.iter)
+    ok = a.status_val == 1
+    assert ok.sum() > len(ok) // 2
+    np.testing.assert_array_equal(a.x[ok], b.x[ok])  # bit for bit: same chunk-to-wave assignment, chains and reduction order
+    np.testing.assert_array_equal(a.y[ok], b.y[ok])
+    np.testing.assert_array_equal(a.lower[ok], b.lower[ok])
+
+
+def test_batched_persistent_chunks_equal_the_launches(monkeypatch):
+    """Config 3's wave with the lock-step iterations of a chunk as ONE persistent launch (kbp1: iterates in registers,
+    256 columns; kbp: 512 columns, two tiles per group) against two launches per iteration: the same bits.  Then with a
+    workgroup that never shows up (fault injection): the launch is called off within 100 ms, nothing was modified, the
+    engine goes on with the launches and returns the same wave."""
+    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
+    A, l, u = problems.extended(pr)
+    g0 = _cfg3_engine(pr, A, l, u, 512, 0)
+    assert not g0.factor_stats()["batch_pers"]
+    leaves = _frontier(g0, pr, l, u, 256)[:256]
+    L = np.stack([lf.l for lf in leaves]); U = np.stack([lf.u for lf in leaves])
+    X = np.stack([lf.x for lf in leaves]); Y = np.stack([lf.y for lf in leaves])
+    ref = g0.solve_batch(L, U, X, Y)
+    g1 = _cfg3_engine(pr, A, l, u, 256, 1)
+    _same_wave(ref, g1.solve_batch(L, U, X, Y))
+    assert g1.batch_pers_fallbacks() == 0 and g1.factor_stats()["batch_pers"]
+    # twice the columns: the general kernel (a group owns two tiles; the iterates live in memory)
+    L2, U2, X2, Y2 = (np.concatenate([v, v[::-1]]) for v in (L, U, X, Y))
+    ref2 = g0.solve_batch(L2, U2, X2, Y2)
+    g2 = _cfg3_engine(pr, A, l, u, 512, 1)
+    _same_wave(ref2, g2.solve_batch(L2, U2, X2, Y2))
+    assert g2.batch_pers_fallbacks() == 0 and g2.factor_stats()["batch_pers"]
+    # one workgroup missing (the flag is read when the batch arrays are made, at the first solve_batch)
+    g3 = _cfg3_engine(pr, A, l, u, 256, 1)
+    monkeypatch.setenv("MIOSQP_COOP_DBG", "64")
+    r3 = g3.solve_batch(L, U, X, Y)
+    monkeypatch.delenv("MIOSQP_COOP_DBG")
+    _same_wave(ref, r3)
+    assert g3.batch_pers_fallbacks() == 1 and not g3.factor_stats()["batch_pers"]
+
+
 def test_batched_search_finds_the_same_optimum():
     """Waves of 8 leaves through solve_batch reach the sequential search's optimum."""
     from miosqp_amd import bnb, dist
