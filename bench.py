@@ -873,6 +873,12 @@ def main():
                     us, by = eng.time_kernel(10 + k, 30)
                     bk.append(dict(kernel=nm, usec=round(us, 2), bytes=by, gbs=round(by / us * 1e-3, 1)))
             batched["kernels_full_width_back_to_back"] = bk
+            batched["sweeps"] = ("one persistent launch per chunk of check_termination iterations, factor in registers and LDS "
+                                 "(kbp1)" if fs.get("batch_pers") else "two launches per lock-step iteration (kbm_fwd, kbm_bwd)")
+            batched["persistent_fallbacks"] = eng.batch_pers_fallbacks()
+            if fs.get("batch_pers") and not args.no_probes:
+                us, _ = eng.time_kernel(15, 100)
+                batched["persistent_sweeps_us_per_lockstep_iter"] = round(us, 2)
             # SURVEY 8d's config-3 accounting: matrix terms once per lock-step iteration, vector terms per column;
             # flops: both sweeps, 2 flop per factor entry (product form: n M + n (n - 1) / 2 entries per sweep)
             nn, MM = cfg["n"], cfg["m"] + cfg["p"]

@@ -1408,7 +1408,7 @@ int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_it
 }
 
 int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, double *usec, double *bytes) {
-  if (!e || which < 0 || (which > 4 && which < 10) || which > 14 || reps <= 0 || !usec) return MIOSQP_EARG;
+  if (!e || which < 0 || (which > 4 && which < 10) || which > 15 || reps <= 0 || !usec) return MIOSQP_EARG;
   ENTER(e);
   if (which >= 10 && e->Bcap == 0) {
     g_err = "time_kernel: batched kernels need a prior solve_batch";
@@ -1442,7 +1442,17 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
       default: launch_iteration(e); break;
     }
   };
-  if ((e->coop || e->pers) && which == 4) {  // `reps` iterations of the single-launch solver in ONE launch, no tests
+  if (which == 15) {  // `reps` lock-step iterations of the batched sweeps in ONE persistent launch (kbp), every column live
+    if (!e->kbp) {
+      g_err = "time_kernel: the persistent batched sweeps are not in use on this engine";
+      return MIOSQP_EARG;
+    }
+    launch_kbp(e, d, ntiles, 5);
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    launch_kbp(e, d, ntiles, reps < 200 ? reps : 200);
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    reps = reps < 200 ? reps : 200;
+  } else if ((e->coop || e->pers) && which == 4) {  // `reps` iterations of the single-launch solver in ONE launch, no tests
     if (e->coop) launch_coop(e, 5, 0, 0); else launch_pers(e, 5, 0, 0);
     HIPCHK(hipEventRecord(e->ev0, e->stream));
     if (e->coop) launch_coop(e, reps, 0, 0); else launch_pers(e, reps, 0, 0);
@@ -1470,7 +1480,8 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
       const double mat[5] = {np * 12 + (n + 1) * 4, nt * 12 + (n + 1) * 4, nt * 12 + (n + 1) * 4,
                              np * 12 + (M + 1) * 4, 2 * (np + nt) * 12 + 2 * (n + M + 1) * 4 + (n + M) * 12};
       const double vec[5] = {(M + 3 * n) * 8, 3 * n * 8, 5 * n * 8, (n + 10 * M) * 8, (6 * n + 16 * M) * 8};
-      *bytes = mat[which - 10] + B * vec[which - 10];
+      const int wb = which == 15 ? 14 : which;
+      *bytes = mat[wb - 10] + B * vec[wb - 10];
       if (e->fold && which < 14)
         *bytes = which == 10 ? mat[0] + mat[1] + B * (vec[0] + vec[1])
                  : which == 11 ? mat[2] + mat[3] + B * (vec[2] + vec[3]) : 0.0;
