@@ -609,17 +609,20 @@ def main():
 
     # A driver-sized run (--steps 20 .. 150) ends before the first tree of the timed region closes (seed 0: ~220 nodes):
     # one more tree, from its root to the end, timed on its own -- what branch and bound buys, next to the rates
-    if hosted and world == 1 and len(closed) < 2:
+    # (config 2 only: a tree of the n = 5000 / 8000 shapes is thousands of 15-40 ms nodes; never more than 20 s; not with
+    #  --no-probes: the profiled node-only runs hold the launches of the timed workload and nothing else)
+    if hosted and world == 1 and len(closed) < 2 and args.config == "cfg2" and not args.no_probes:
         next_instance(head)
         torch.cuda.synchronize()
         tn0, ti0 = head.hs.nodes, head.hs.iters
         tt0 = time.perf_counter()
-        while head.hs.step(10 ** 6) != 0:
-            pass
+        open_left = 1
+        while open_left != 0 and time.perf_counter() - tt0 < 20.0:
+            open_left = head.hs.step(256)
         torch.cuda.synchronize()
         tdt = time.perf_counter() - tt0
         trees["one_tree_after_the_timed_region"] = dict(ms_to_close=round(1e3 * tdt, 3), nodes=head.hs.nodes - tn0,
-                                                       iters=head.hs.iters - ti0,
+                                                       iters=head.hs.iters - ti0, closed=bool(open_left == 0),
                                                        upper_glob=float(model.work.upper_glob))
         next_instance(head)
 
