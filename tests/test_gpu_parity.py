@@ -1882,6 +1882,10 @@ def test_streaming_batch_at_config3_size(oracle_mod):
     # useful column-iterations / (columns x lock-step iterations): the stream keeps the columns busy once the
     # frontier is wide enough (a wave of 256 leaves averages below one half)
     assert node_iters <= 256 * lock_iters
+    # the chunks ran as persistent launches (§3e'), or were called off once for the launches when a replayed node's
+    # cooperative launch held CUs at the wrong moment -- either way the nodes above were right
+    print("persistent sweeps in use at the end: %s, called off %d time(s)" % (eng.factor_stats()["batch_pers"], eng.batch_pers_fallbacks()))
+    assert eng.batch_pers_fallbacks() <= 1
 
 
 @pytest.mark.parametrize("name", [c for c in case_names() if "x0" in c or "n10" in c or "n12" in c or "n20" in c or "mpc" in c])
