@@ -145,6 +145,7 @@ struct Dev {
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
   double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_rx, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
+  double *b_xfs;  // harvest tile: D^-1 (clamped x), next to b_xis = D^-1 (rounded candidate)
   double *b_sm, *b_sn;      // 8 x M x Bs, 4 x n x Bs
   double *b_xfin, *b_yfin;  // unscaled answers, batch-fastest
   double *b_xi, *b_xis;     // rounded candidates (node digest), unscaled / scaled
