@@ -506,6 +506,41 @@ def test_batched_persistent_chunks_equal_the_launches(monkeypatch):
     assert g3.batch_pers_fallbacks() == 1 and not g3.factor_stats()["batch_pers"]
 
 
+@pytest.mark.parametrize("n,m,p,dens,B,idrows", [(401, 590, 62, 0.15, 256, True), (300, 709, 105, 0.4, 320, False),
+                                                   (100, 62, 42, 0.4, 256, True), (512, 1000, 200, 0.7, 192, True)])
+def test_batched_persistent_chunks_over_shapes(monkeypatch, n, m, p, dens, B, idrows):
+    """The persistent batched sweeps against the launches inside their limits (n <= 512, rows in the products <= 1024):
+    odd sizes, with and without the identity-row shortcut, one and two column tiles per group, waves of random 0/1
+    fixings -- the same bits (tools/probes/soak_kbp.py runs more of them)."""
+    from miosqp_amd import qp
+    if not idrows:
+        monkeypatch.setenv("MIOSQP_NO_IDROWS", "1")
+    pr = problems.random_miqp(n, m, p, density=dens, seed=n + m)
+    A, l, u = problems.extended(pr)
+    rng = np.random.RandomState(p)
+    L = np.tile(l, (B, 1)); U = np.tile(u, (B, 1))
+    for b in range(B):
+        idx = rng.choice(p, size=min(p, 1 + b % 6), replace=False)
+        val = rng.randint(0, 2, size=len(idx)).astype(float)
+        L[b, m + idx] = val
+        U[b, m + idx] = val
+    X = np.zeros((B, n)); Y = np.zeros((B, m + p))
+    out = []
+    for bp in (0, 1):
+        g = qp.OSQP()
+        g.setup(pr["P"], pr["q"], A, l, u, **dict(problems.QP_SETTINGS, max_batch=max(B, 256), batch_pers=bp, max_iter=500))
+        g.set_integer_rows(pr["i_idx"], m)
+        g.set_root(l, u, 1e-3, 1e-3)
+        out.append(g.solve_batch(L, U, X, Y))
+        assert g.factor_stats()["batch_pers"] == bool(bp) and g.batch_pers_fallbacks() == 0
+        g.close()
+    a, b_ = out
+    np.testing.assert_array_equal(a.status_val, b_.status_val)
+    np.testing.assert_array_equal(a.iter, b_.iter)
+    np.testing.assert_array_equal(a.x, b_.x)
+    np.testing.assert_array_equal(a.y, b_.y)
+
+
 def test_batched_search_finds_the_same_optimum():
     """Waves of 8 leaves through solve_batch reach the sequential search's optimum."""
     from miosqp_amd import bnb, dist
