@@ -754,8 +754,10 @@ def main():
             rngs = [np.random.RandomState(args.seed + 777) for _ in range(args.pools)]
 
             def make_model():
-                # (the one-launch-per-chunk sweeps need the whole chip to themselves: two pools take the launches)
-                return setup_model(prob, dict(qs, batch_pers=0), backend=None)[0]
+                # (each pool's chunk is one persistent launch that takes the whole chip: the two pools' launches take turns,
+                #  a pool's test / harvest / refill runs under the other pool's sweeps; were two launches ever to split the
+                #  CUs between them, both are called off within 100 ms and those engines go on with two launches per iteration)
+                return setup_model(prob, dict(qs), backend=None)[0]
 
             def reroot(k, mdl):
                 r = rngs[k]  # every pool draws the same numbers
@@ -782,7 +784,8 @@ def main():
                 node_iters_per_s=round(it / dtp, 1), nodes_per_s=round(nd / dtp, 2),
                 device_us_per_lockstep_iter_per_pool=[round(1e3 * s3[0] / max(1, s3[1]), 2) for s3 in st3],
                 column_occupancy=[round(s3[2] / float(max(1, args.batch_width * s3[1])), 3) for s3 in st3],
-                leaves_moved=[sh_.moved for sh_ in mp.sh])
+                leaves_moved=[sh_.moved for sh_ in mp.sh],
+                persistent_fallbacks=[mdl.work.solver.batch_pers_fallbacks() for mdl in mp.models])
             for mdl in mp.models:
                 mdl.work.solver.close()
         model.work.leaves = []  # the pool owns the open leaves of this instance
