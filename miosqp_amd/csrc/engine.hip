@@ -263,18 +263,28 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->x_tail) hipGraphExecDestroy(e->x_tail);
   if (e->g_full) hipGraphDestroy(e->g_full);
   if (e->g_tail) hipGraphDestroy(e->g_tail);
-  for (void *p : e->allocs) {
-    bool parked = false;
-    for (const ParkedChunk &c : e->chunks)
-      if (c.p == p && c.bytes <= CHUNK_PARK_MAX && !getenv("MIOSQP_NO_CACHE")) {
-        std::lock_guard<std::mutex> lk(g_rt_mutex);
-        if (g_chunk_cache.size() < 8) {
-          g_chunk_cache.push_back(c);
-          parked = true;
+  {
+    // small pool chunks are parked for the next engine of the process, zero-filled HERE (outside anybody's set-up time):
+    // fill on the engine's stream, wait, then offer them
+    std::vector<ParkedChunk> park;
+    for (void *p : e->allocs) {
+      bool keep = false;
+      for (const ParkedChunk &c : e->chunks)
+        if (c.p == p && c.bytes <= CHUNK_PARK_MAX && park.size() < 8 && !getenv("MIOSQP_NO_CACHE")) {
+          keep = hipMemsetAsync(c.p, 0, c.bytes, e->stream) == hipSuccess;
+          if (keep) park.push_back(c);
+          break;
         }
-        break;
+      if (!keep) hipFree(p);
+    }
+    if (!park.empty()) {
+      const bool filled = hipStreamSynchronize(e->stream) == hipSuccess;
+      std::lock_guard<std::mutex> lk(g_rt_mutex);
+      for (const ParkedChunk &c : park) {
+        if (filled && g_chunk_cache.size() < 8) g_chunk_cache.push_back(c);
+        else hipFree(c.p);
       }
-    if (!parked) hipFree(p);
+    }
   }
   drop_stream_graph(e);
   for (hipEvent_t ev : e->ev_pool)
@@ -302,6 +312,9 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   delete e;
   return 0;
 }
+
+static int stage_wait(miosqp_qp_engine *e, int k);
+static int stage_mark(miosqp_qp_engine *e, int k);
 
 int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t *Pp, const int32_t *Pi,
                     const double *Px, const int32_t *Ap, const int32_t *Ai, const double *Ax,
@@ -473,13 +486,31 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   }
   tick("stream, events, pinned buffers");
   // scaled q, raw q, scaled bounds
-  HIPCHK(hipMemcpy(d.q, e->sc.q.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d.qraw, q, sizeof(double) * n, hipMemcpyHostToDevice));
-  if (M > 0) {
-    HIPCHK(hipMemcpy(d.raw_l, l, sizeof(double) * M, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d.raw_u, u, sizeof(double) * M, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_scale_bounds, dim3((M + 255) / 256), dim3(256), 0, e->stream, d);
+  if (e->rt.in_cap >= 2 * (size_t)M + 2 * (size_t)n) {
+    // through the pinned staging block on the engine's stream (four blocking copies from pageable memory were ~40 us of
+    // a small problem's set-up): [ l | u ] in region 0, [ scaled q | q ] in region 1, marked busy until the copies are out
+    double *h = e->h_in;
+    memcpy(h, l, sizeof(double) * M);
+    memcpy(h + M, u, sizeof(double) * M);
+    memcpy(h + 2 * (size_t)M, e->sc.q.data(), sizeof(double) * n);
+    memcpy(h + 2 * (size_t)M + n, q, sizeof(double) * n);
+    if (M > 0) {
+      HIPCHK(hipMemcpyAsync(d.raw_l, h, sizeof(double) * M, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(d.raw_u, h + M, sizeof(double) * M, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipMemcpyAsync(d.q, h + 2 * (size_t)M, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.qraw, h + 2 * (size_t)M + n, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+    if (int rcm = stage_mark(e, 0)) { miosqp_qp_cleanup(e); return rcm; }
+    if (int rcm = stage_mark(e, 1)) { miosqp_qp_cleanup(e); return rcm; }
+  } else {
+    HIPCHK(hipMemcpy(d.q, e->sc.q.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.qraw, q, sizeof(double) * n, hipMemcpyHostToDevice));
+    if (M > 0) {
+      HIPCHK(hipMemcpy(d.raw_l, l, sizeof(double) * M, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d.raw_u, u, sizeof(double) * M, hipMemcpyHostToDevice));
+    }
   }
+  if (M > 0) hipLaunchKernelGGL(k_scale_bounds, dim3((M + 255) / 256), dim3(256), 0, e->stream, d);
   hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, d);
   e->tpr_pv = pick_tpr((double)f.nnz_panel / n);
   e->tpr_pc = pick_tpr(M > 0 ? (double)f.nnz_panel / M : 1.0);
@@ -756,8 +787,16 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
   ENTER(e);
   for (int k = 0; k < n_int; k++)
     if (i_idx[k] < 0 || i_idx[k] >= e->n) return MIOSQP_EARG;
-  if (n_int) HIPCHK(hipMemcpy((void *)e->d.i_idx, i_idx, sizeof(int) * n_int, hipMemcpyHostToDevice));
   e->h_iidx.assign(i_idx, i_idx + n_int);  // host copy (the streaming driver rounds an incumbent's integer entries)
+  // uploads through region 1 of the pinned staging block when they fit (three blocking copies were ~30 us of a small set-up):
+  // [ i_idx (n_int ints) | int_pos (n ints) | a_int (n doubles, below) ]
+  const size_t stage_doubles = e->rt.in_cap > 2 * (size_t)e->M ? e->rt.in_cap - 2 * (size_t)e->M : 0;
+  const size_t ints_doubles = ((size_t)n_int + (size_t)e->n + 1) / 2;
+  const bool staged = stage_doubles >= ints_doubles + (size_t)e->n;
+  double *const stage = e->h_in + 2 * (size_t)e->M;
+  if (staged) {
+    if (int rcw = stage_wait(e, 1)) return rcw;
+  }
   {
     std::vector<int> pos(e->n, -1);
     for (int k = 0; k < n_int; k++) pos[i_idx[k]] = k;
@@ -767,7 +806,16 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
       if (rc) return rc;
       e->d.int_pos = ip;
     }
-    HIPCHK(hipMemcpy((void *)e->d.int_pos, pos.data(), sizeof(int) * e->n, hipMemcpyHostToDevice));
+    if (staged) {
+      int *hi = reinterpret_cast<int *>(stage);
+      memcpy(hi, i_idx, sizeof(int) * n_int);
+      memcpy(hi + n_int, pos.data(), sizeof(int) * e->n);
+      if (n_int) HIPCHK(hipMemcpyAsync((void *)e->d.i_idx, hi, sizeof(int) * n_int, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync((void *)e->d.int_pos, hi + n_int, sizeof(int) * e->n, hipMemcpyHostToDevice, e->stream));
+    } else {
+      if (n_int) HIPCHK(hipMemcpy((void *)e->d.i_idx, i_idx, sizeof(int) * n_int, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy((void *)e->d.int_pos, pos.data(), sizeof(int) * e->n, hipMemcpyHostToDevice));
+    }
   }
   e->d.n_int = n_int;
   e->d.m_orig = m_orig;
@@ -794,7 +842,12 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
       int rc = dalloc(e, &f2, (size_t)n * ld2 + 64);
       if (!rc) rc = dalloc(e, &ai, (size_t)n);
       if (rc) return rc;
-      HIPCHK(hipMemcpy(ai, aint.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+      if (staged) {
+        memcpy(stage + ints_doubles, aint.data(), sizeof(double) * n);
+        HIPCHK(hipMemcpyAsync(ai, stage + ints_doubles, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+      } else {
+        HIPCHK(hipMemcpy(ai, aint.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+      }
       hipLaunchKernelGGL(k_drop_bound_columns, dim3((ld2 + 255) / 256, n), dim3(256), 0, e->stream, e->d.f_rows, e->d.ldf,
                          f2, ld2, m, n_int, n);
       // (no wait: every reader of f2 is a later kernel on this stream)
@@ -805,6 +858,7 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
     }
   }
   // the captured graphs hold Dev by value but never read n_int / m_orig / i_idx contents
+  if (staged) return stage_mark(e, 1);
   return 0;
 }
 
