@@ -852,9 +852,13 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                    nodes_per_s=round(nodes / dt_max, 2), iters_per_node=round(iters / max(1.0, nodes), 1),
                    nodes=nodes, trees=trees,
-                   config=dict(workload="BASELINE configs[1]: random_miqp n=%d m=%d p=%d density %.2f seed %d, "
+                   config=dict(workload="%s: random_miqp n=%d m=%d p=%d density %.2f seed %d, "
                                         "%s per rank per step, leaves sharded over %d GPU(s)" %
-                                        (cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed,
+                                        ({"cfg1": "BASELINE configs[0]'s shape on the GPU", "cfg2": "BASELINE configs[1]",
+                                          "cfg5": "BASELINE configs[4]",
+                                          "cfg5x": "not a BASELINE config (configs[4]'s shape beyond the Infinity Cache)"}
+                                         [args.config],
+                                         cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed,
                                          ("node relaxations for %.1f ms" % args.step_budget_ms) if budget
                                          else "%d node(s)" % args.wave, world),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],

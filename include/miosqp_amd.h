@@ -305,8 +305,17 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
  * bit 2 = dense setup stages ran on the device, bit 3 = cooperative solver in use, bits 8..15 = its calibrated
  * poll delay (64-clock units); out[8] = bytes per iteration the kernels of the form in use actually request (dense
  * blocks carry no index array: 8 B per entry instead of the formula's 12); out[9] = times the engine fell back from
- * the cooperative form.  out must hold 10 values. */
+ * the cooperative form; out[7] bit 17 = the explicit KKT inverse failed its residual check at set-up and the engine
+ * iterates with the factor's sweeps instead (see miosqp_qp_get_inverse_guard).  out must hold 10 values. */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
+
+/* The register-resident solvers iterate on the explicit inverse of the scaled KKT matrix (sigma = 1e-6), which -- unlike
+ * the sweeps with the LDL^T factor the reference's linear solver performs at /root/reference/miosqp/workspace.py:63-68
+ * (osqp.setup) and node.py:108 (solve) -- is not backward stable.  At set-up the device measures
+ * max |K W r - r| / max |r| over three probe vectors; above the threshold (1e-9; MIOSQP_GUARD_TOL overrides, negative
+ * switches the check off) the engine does not use the inverse.  out[0] = measured residual (-1: no inverse was built),
+ * out[1] = threshold, out[2] = 1 when the engine fell back.  out must hold 3 values. */
+int miosqp_qp_get_inverse_guard(miosqp_qp_engine *e, double *out);
 
 /* Times `reps` back-to-back launches of one hot-path kernel with HIP events on the engine's
  * own stream and returns the mean duration in microseconds in *usec and the kernel's
@@ -327,7 +336,10 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters,
                               int64_t *node_iters, int32_t reset);
 
-/* debug counters: which = 0 -> number of wave compactions solve_batch has performed */
+/* debug counters: which = 0 -> wave compactions solve_batch has performed; 1 -> times a chunk's persistent launch was
+ * called off; 2 -> whole-chip launches on this engine's device that were ordered behind another engine's (engines of
+ * one process take turns with k_coop / k_pers / kbp); 3 -> the control block's call-off word once the engine's stream
+ * is idle (blocks); 4 -> engines of this device that take turns */
 int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which);
 
 /* debug: per-workgroup (start, end) stamps (100 MHz wall clock) of ONE launch of a product-form

@@ -100,6 +100,7 @@ SYMBOLS = {
     "miosqp_qp_debug_iterate": (C.c_int, [C.c_void_p, C.c_int32, dp, dp, dp]),
     "miosqp_qp_get_scaling": (C.c_int, [C.c_void_p, dp, dp, dp]),
     "miosqp_qp_get_factor_stats": (C.c_int, [C.c_void_p, i64p]),
+    "miosqp_qp_get_inverse_guard": (C.c_int, [C.c_void_p, dp]),
     "miosqp_qp_get_loop_stats": (C.c_int, [C.c_void_p, dp, i64p, C.c_int32]),
     "miosqp_qp_get_batch_stats": (C.c_int, [C.c_void_p, dp, i64p, i64p, C.c_int32]),
     "miosqp_qp_debug_counter": (C.c_int64, [C.c_void_p, C.c_int32]),

@@ -523,7 +523,9 @@ class MIOSQP(object):
         engine every tree runs in one launch -- one workgroup (one wavefront for n + M <= 64) per instance,
         `miosqp_qp_solve_trees` --, so that many small independent MIQPs fill the chip instead of one compute unit;
         instances the launch cannot hold (leaf list overflow) and engines without the entry point go through the
-        sequential calls.  The model itself is left as it was (its q, l, u, leaves and statistics are not touched).
+        sequential calls.  The model itself is left as it was: the one-launch path touches nothing of it, the sequential
+        fallback puts q, l, u, the leaf list and the statistics back when it is done or when an instance raises (leaves of
+        an unfinished device-hosted search are placeholders and not resumable either way).
         Returns a list of dicts: x, upper_glob, status, nodes, osqp_iter, run_time."""
         work, data, st = self.work, self.work.data, self.work.settings
         B = len(instances)
@@ -574,7 +576,9 @@ class MIOSQP(object):
                         redo.append(k)
                         continue
                     upper = info.upper_glob
-                    finished = info.leaves_left == 0
+                    # workspace.py:352-373 decides on the loop counter, not on the leaf list: a tree that closes with its
+                    # last permitted node reports the MAX_ITER family, exactly as solve() does (iter_num = nodes + 1)
+                    finished = int(info.nodes) + 1 < st['max_iter_bb']
                     if upper != np.inf:
                         status = MI_SOLVED if finished else MI_MAX_ITER_FEASIBLE
                     elif upper >= 0:
@@ -589,15 +593,23 @@ class MIOSQP(object):
         if redo:
             # sequential path on a copy of the model's vectors, restored afterwards
             q_keep, l_keep, u_keep = data.q, data.l[:m].copy(), data.u[:m].copy()
-            for k in redo:
-                inst = instances[k]
-                self.update_vectors(q=Q[k].copy(), l=L[k, :m].copy(), u=U[k, :m].copy())
-                if inst.get('x0') is not None:
-                    self.set_x0(np.asarray(inst['x0'], dtype=float).copy())
-                res = self.solve()
-                out[k] = dict(x=np.array(res.x, dtype=float), upper_glob=res.upper_glob, status=res.status,
-                              nodes=work.iter_num - 1, osqp_iter=work.osqp_iter, run_time=res.run_time)
-            self.update_vectors(q=q_keep, l=l_keep, u=u_keep)
+            # what solve() / update_vectors() overwrite: put back whatever happens (an instance with l > u raises)
+            names = ('leaves', 'x', 'upper_glob', 'lower_glob', 'status', 'iter_num', 'osqp_iter', 'osqp_solve_time',
+                     'solve_time', 'run_time', 'first_run', 'osqp_iter_avg', 'defer_lower')
+            keep = {a: getattr(work, a) for a in names if hasattr(work, a)}
+            try:
+                for k in redo:
+                    inst = instances[k]
+                    self.update_vectors(q=Q[k].copy(), l=L[k, :m].copy(), u=U[k, :m].copy())
+                    if inst.get('x0') is not None:
+                        self.set_x0(np.asarray(inst['x0'], dtype=float).copy())
+                    res = self.solve()
+                    out[k] = dict(x=np.array(res.x, dtype=float), upper_glob=res.upper_glob, status=res.status,
+                                  nodes=work.iter_num - 1, osqp_iter=work.osqp_iter, run_time=res.run_time)
+            finally:
+                self.update_vectors(q=q_keep, l=l_keep, u=u_keep)
+                for a, v in keep.items():
+                    setattr(work, a, v)
         return out
 
     def update_vectors(self, q=None, l=None, u=None):

@@ -186,6 +186,7 @@ struct Dev {
 #include "kernels_iter.inc"  // device helpers; the four kernels of the factor form and the two of the product form
 #include "kernels_test.inc"  // termination test of the multi-kernel forms (k_check_*), Norms / decide_status shared by all forms
 #include "kernels_coop.inc"  // cooperative register-resident solver (k_coop) and its in-kernel termination test
+#include "kernels_guard.inc"  // residual check of the explicit KKT inverse at set-up (falls back to the sweeps when it fails)
 #include "kernels_pers.inc"  // persistent streaming solver (k_pers): one launch per solve, the factor read from memory every iteration
 #include "kernels_resident.inc"  // LDS-resident single-workgroup solver (k_resident)
 #include "kernels_node.inc"  // per-solve prologue / epilogue kernels (scaling, warm start, finish, node digest, objective)
@@ -259,6 +260,7 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (!e) return 0;
   if (e->device >= 0) (void)hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
+  chip_quit(e);
   if (e->x_full) hipGraphExecDestroy(e->x_full);
   if (e->x_tail) hipGraphExecDestroy(e->x_tail);
   if (e->g_full) hipGraphDestroy(e->g_full);
@@ -568,15 +570,29 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
             d.W = Wd;
             d.Kc = Kc;
             hipLaunchKernelGGL(k_build_kc, dim3((n + M + 255) / 256, n + M), dim3(256), 0, e->stream, d, Kc);
+            // the explicit inverse is checked before it is used (kernels_guard.inc); when it fails the workgroup keeps
+            // the product-form sweeps in LDS, if they fit
+            rc = inverse_guard(e);
+            if (rc) { miosqp_qp_cleanup(e); return rc; }
+            if (e->guard_tripped) {
+              d.W = nullptr;
+              d.Kc = nullptr;
+              e->res_sp_off = -1;
+              const size_t need2 = resident_lds_doubles(n, M, false) * sizeof(double);
+              if (need2 <= 160 * 1024) e->res_lds = need2;
+              else e->resident = false;
+            }
           }
-          HIPCHK(lds_limit_once((const void *)k_resident, 0));
-          // lanes per row: as many as keep every row of a sweep in flight at once
-          auto pow2_floor = [](int v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
-          e->res_tg1 = std::min(64, std::max(1, pow2_floor(RES_THREADS / n)));
-          e->res_tg2 = std::min(64, std::max(1, pow2_floor(RES_THREADS / (n + M))));
-          if (const char *ev = getenv("MIOSQP_RES_TG")) {
-            int a1 = 0, b1 = 0;
-            if (sscanf(ev, "%d,%d", &a1, &b1) == 2) { e->res_tg1 = a1; e->res_tg2 = b1; }
+          if (e->resident) {
+            HIPCHK(lds_limit_once((const void *)k_resident, 0));
+            // lanes per row: as many as keep every row of a sweep in flight at once
+            auto pow2_floor = [](int v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
+            e->res_tg1 = std::min(64, std::max(1, pow2_floor(RES_THREADS / n)));
+            e->res_tg2 = std::min(64, std::max(1, pow2_floor(RES_THREADS / (n + M))));
+            if (const char *ev = getenv("MIOSQP_RES_TG")) {
+              int a1 = 0, b1 = 0;
+              if (sscanf(ev, "%d,%d", &a1, &b1) == 2) { e->res_tg1 = a1; e->res_tg2 = b1; }
+            }
           }
         }
       }
@@ -642,6 +658,16 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           d.W = Wd;
           d.Kc = Kc;
           hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
+          // the explicit inverse is checked before it is used (kernels_guard.inc); when it fails this engine iterates
+          // with the sweeps of the product form (two launches per iteration) instead
+          rc = inverse_guard(e);
+          if (rc) { miosqp_qp_cleanup(e); return rc; }
+          if (e->guard_tripped) {
+            e->coop = false;
+            e->coop_capable = false;
+            d.W = nullptr;
+            d.Kc = nullptr;
+          }
         }
       }
       if (const char *ev = getenv("MIOSQP_BD_CFG")) e->bd_cfg = atoi(ev);
@@ -684,6 +710,10 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   if (!e->resident && !e->coop && !e->pers) {  // the single-launch solvers need no captured chunk
     int rc = capture_chunk(e, e->chunk, &e->g_full, &e->x_full);
     if (!rc && e->tail_iters > 0) rc = capture_chunk(e, e->tail_iters, &e->g_tail, &e->x_tail);
+    if (rc) { miosqp_qp_cleanup(e); return rc; }
+  }
+  if (e->coop_capable || e->pers_capable) {  // whole-chip launches of one process take turns (host.inc: ChipTurn)
+    int rc = chip_join(e);
     if (rc) { miosqp_qp_cleanup(e); return rc; }
   }
   if (e->coop) {
@@ -880,7 +910,7 @@ int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *
     HIPCHK(hipMemcpyAsync(e->d.root_u, e->h_in + e->M, sizeof(double) * e->M, hipMemcpyHostToDevice, e->stream));
     if (int rcm = stage_mark(e, 0)) return rcm;
   }
-  if (e->x_stream && (e->d.eps_int != eps_int_feas || e->d.eps_lin != eps_lin)) drop_stream_graph(e);  // captured by value
+  if ((e->x_stream || e->x_stream_a) && (e->d.eps_int != eps_int_feas || e->d.eps_lin != eps_lin)) drop_stream_graph(e);  // captured by value
   e->d.eps_int = eps_int_feas;
   e->d.eps_lin = eps_lin;
   e->d.digest = 1;
@@ -980,7 +1010,7 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     if (l[i] > u[i]) return MIOSQP_EBOUNDS;
   const double t0 = wall();
   // n + M <= 64: the whole search in ONE wavefront on the explicit KKT inverse (k_tree_w); MIOSQP_TREE_WAVE=0 keeps k_tree
-  const bool wave = n + M <= TW && !(getenv("MIOSQP_TREE_WAVE") && atoi(getenv("MIOSQP_TREE_WAVE")) == 0);
+  bool wave = n + M <= TW && !e->guard_tripped && !(getenv("MIOSQP_TREE_WAVE") && atoi(getenv("MIOSQP_TREE_WAVE")) == 0);
   if (wave && !e->d.Kc) {  // an engine in the LDS-resident form has not built Kc (and perhaps W) yet
     Dev &d = e->d;
     const int N = n + M;
@@ -996,6 +1026,12 @@ int miosqp_qp_solve_tree(miosqp_qp_engine *e, const double *l, const double *u, 
     d.W = Wd;
     d.Kc = Kc;
     hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
+    if (int rcg = inverse_guard(e)) return rcg;
+    if (e->guard_tripped) {  // (kernels_guard.inc) the explicit inverse failed its check: the workgroup kernel with the sweeps
+      d.W = nullptr;
+      d.Kc = nullptr;
+      wave = false;
+    }
   }
   if (!e->tree_ready) {
     HIPCHK(lds_limit_once((const void *)k_tree, 1));
@@ -1178,7 +1214,7 @@ int miosqp_qp_solve_trees(miosqp_qp_engine *e, int32_t B, const double *q, const
   for (size_t k = 0; k < (size_t)B * M; k++)
     if (l[k] > u[k]) return MIOSQP_EBOUNDS;
   const double t0 = wall();
-  const bool wave = n + M <= TW && !(getenv("MIOSQP_TREE_WAVE") && atoi(getenv("MIOSQP_TREE_WAVE")) == 0);
+  bool wave = n + M <= TW && !e->guard_tripped && !(getenv("MIOSQP_TREE_WAVE") && atoi(getenv("MIOSQP_TREE_WAVE")) == 0);
   if (wave && !e->d.Kc) {  // as miosqp_qp_solve_tree: an engine in the LDS-resident form has not built Kc (and perhaps W) yet
     Dev &d = e->d;
     const int N = n + M;
@@ -1194,6 +1230,12 @@ int miosqp_qp_solve_trees(miosqp_qp_engine *e, int32_t B, const double *q, const
     d.W = Wd;
     d.Kc = Kc;
     hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
+    if (int rcg = inverse_guard(e)) return rcg;
+    if (e->guard_tripped) {  // (kernels_guard.inc) the explicit inverse failed its check: the workgroup kernel with the sweeps
+      d.W = nullptr;
+      d.Kc = nullptr;
+      wave = false;
+    }
   }
   if (!wave) HIPCHK(lds_limit_once((const void *)k_tree, 1));
   if (B > e->tb_cap) {  // (a larger batch takes new arrays; the old ones stay with the pool until cleanup)
@@ -1370,7 +1412,15 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[3] = (int64_t)b[4];
   out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0) |
            (e->pers ? 16 : 0) | ((e->pers && e->pp.sinv) ? 32 : 0) | ((e->pers && e->pp.small) ? 64 : 0) |
-           ((e->d.coop_nap & 0xff) << 8) | (e->kbp ? (1 << 16) : 0);
+           ((e->d.coop_nap & 0xff) << 8) | (e->kbp ? (1 << 16) : 0) | (e->guard_tripped ? (1 << 17) : 0);
+  return 0;
+}
+
+int miosqp_qp_get_inverse_guard(miosqp_qp_engine *e, double *out) {
+  if (!e || !out) return MIOSQP_EARG;
+  out[0] = e->guard_resid;
+  out[1] = e->guard_tol;
+  out[2] = e->guard_tripped ? 1.0 : 0.0;
   return 0;
 }
 
@@ -1446,6 +1496,25 @@ int miosqp_qp_debug_clock(miosqp_qp_engine *e, double *cycles, double *ticks) {
 // debug counters: 0 = wave compactions performed by solve_batch so far
 int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which) {
   if (!e) return -1;
+  if (which == 2) {  // whole-chip launches of this device that were ordered behind another stream's (host.inc: ChipTurn)
+    ChipTurn *t = chip_of(e);
+    if (!t) return -1;
+    std::lock_guard<std::mutex> lk(t->mu);
+    return t->waits;
+  }
+  if (which == 3) {  // the control block's call-off / time-out word, after everything queued on the engine's stream
+    if (e->device >= 0 && hipSetDevice(e->device) != hipSuccess) return -1;
+    int pad = -1;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return -1;
+    if (hipMemcpy(&pad, &e->d.ctrl->pad, sizeof pad, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return pad;
+  }
+  if (which == 4) {  // engines of this device that take turns
+    ChipTurn *t = chip_of(e);
+    if (!t) return -1;
+    std::lock_guard<std::mutex> lk(t->mu);
+    return t->users;
+  }
   return which == 0 ? e->compactions : which == 1 ? e->kbp_fallbacks : -1;
 }
 

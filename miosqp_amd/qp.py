@@ -397,7 +397,13 @@ class OSQP(object):
                     bytes_per_iter=int(out[3]), bytes_moved_per_iter=int(out[8]), coop_fallbacks=int(out[9]),
                     tpr=(int(out[4]), int(out[5]), int(out[6])),
                     fold=bool(out[7] & 1), resident=bool(out[7] & 2), setup_on_device=bool(out[7] & 4), coop=bool(out[7] & 8), pers=bool(out[7] & 16), tail_inverse=bool(out[7] & 32), pers_small=bool(out[7] & 64), coop_nap=(out[7] >> 8) & 0xff,
-                    batch_pers=bool(out[7] & (1 << 16)))
+                    batch_pers=bool(out[7] & (1 << 16)), inverse_guard_tripped=bool(out[7] & (1 << 17)))
+
+    def inverse_guard(self):
+        """(residual, threshold, tripped) of the set-up check of the explicit KKT inverse; residual -1: none was built."""
+        out = np.zeros(3)
+        _check(self._lib.miosqp_qp_get_inverse_guard(self._h, out.ctypes.data_as(_lib.dp)), "get_inverse_guard")
+        return float(out[0]), float(out[1]), bool(out[2])
 
     def loop_stats(self, reset=False):
         ms, it = C.c_double(), C.c_int64()
@@ -417,6 +423,17 @@ class OSQP(object):
     def batch_pers_fallbacks(self):
         """Times a chunk's persistent launch (kbp) was called off and the engine went back to the launches."""
         return int(self._lib.miosqp_qp_debug_counter(self._h, 1))
+
+    def chip_turn_waits(self):
+        """Whole-chip launches on this engine's device that were ordered behind another engine's (they take turns)."""
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 2))
+
+    def chip_turn_users(self):
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 4))
+
+    def call_off_word(self):
+        """The control block's call-off / time-out word once the engine's stream is idle (0: nothing happened)."""
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 3))
 
     def time_kernel(self, which, reps=200):
         us, by = C.c_double(), C.c_double()

@@ -63,7 +63,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "miosqp_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".inc", ".c", ".cc", ".txt")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# tests pass the CPU oracle", "").lower() or \
                     f in ("bnb.py",), (dirpath, f)

@@ -1,0 +1,269 @@
+"""GPU parity on structured instances (tests/structured_problems.py) in the range the register-resident cooperative
+solver serves (193 <= n + M <= 2048), the set-up guard of the explicit KKT inverse, and the turn-taking of whole-chip
+launches inside one process.  Through the C ABI, against the CPU oracle; tolerances as in test_gpu_parity.py."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import structured_problems as sp
+from miosqp_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+ITER_TOL = 1e-9
+SOL_TOL = 1e-8
+# instances whose KKT matrix is so ill-conditioned (P = 0 or 1e-6 I, fewer rows than variables: eigenvalues of the
+# reduced Hessian at sigma = 1e-6) that the explicit inverse fails its residual check and the engine must fall back
+ILL = ("few_rows_milp", "few_rows_tinyP")
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
+
+
+def _pair(oracle_mod, pr, **kw):
+    from miosqp_amd import qp
+    A, l, u = problems.extended(pr)
+    st = dict(problems.QP_SETTINGS)
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **dict(st, **kw))
+    o.setup(pr["P"], pr["q"], A, l, u, **st)
+    g.set_integer_rows(pr["i_idx"], pr["A"].shape[0])
+    return g, o, A, l, u
+
+
+def _node_chain(g, o, pr, A, l, u, depth=3):
+    """root from zeros, then children with one integer variable fixed per level (the reference's call order:
+    update -> warm_start(parent) -> solve, node.py:102-108): status, iterations, x, y, bound."""
+    n, M, m = A.shape[1], A.shape[0], pr["A"].shape[0]
+    ii, p = pr["i_idx"], len(pr["i_idx"])
+    x, y = np.zeros(n), np.zeros(M)
+    lo, hi = l.copy(), u.copy()
+    rng = np.random.RandomState(1)
+    for level in range(depth):
+        r = g.solve_node(lo, hi, x, y)
+        o.update(l=lo, u=hi)
+        o.warm_start(x=x, y=y)
+        ro = o.solve()
+        assert (r.status_val, r.iter) == (ro.info.status_val, ro.info.iter), level
+        if ro.info.status_val not in (1, -2):
+            return
+        xo = ro.x.copy()
+        xo[ii] = np.minimum(np.maximum(xo[ii], lo[-p:]), hi[-p:])
+        assert rel(r.x, xo) <= SOL_TOL and rel(r.y, ro.y) <= SOL_TOL, level
+        low = 0.5 * xo.dot(pr["P"].dot(xo)) + pr["q"].dot(xo)
+        assert abs(r.lower - low) <= 1e-9 * max(1.0, abs(low)), level
+        k = int(rng.randint(p))
+        lo, hi = lo.copy(), hi.copy()
+        v = np.floor(xo[ii[k]])
+        if level % 2:
+            lo[m + k] = min(v + 1, hi[m + k])
+        else:
+            hi[m + k] = max(v, lo[m + k])
+        x, y = r.x, r.y
+
+
+@pytest.mark.parametrize("name", [c for c in sp.CASES if c not in ILL])
+def test_cooperative_solver_on_structured_instances(oracle_mod, name):
+    """k_coop (explicit inverse in registers) against the oracle where no instance was random-dense: iterates after
+    k in {1, 2, 27, 75} raw iterations from a random warm start, then a chain of node relaxations."""
+    pr = sp.make(name)
+    g, o, A, l, u = _pair(oracle_mod, pr, coop=1, resident=0)
+    n, M = A.shape[1], A.shape[0]
+    assert 193 <= n + M <= 2048
+    fs = g.factor_stats()
+    res, tol, tripped = g.inverse_guard()
+    assert fs["coop"] and not tripped and 0 <= res <= tol, (name, res, tol)
+    rng = np.random.RandomState(5)
+    x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(M)
+    for k in (1, 2, 27, 75):
+        g.warm_start(x=x0, y=y0)
+        o.warm_start(x=x0, y=y0)
+        xg, zg, yg = g.debug_iterate(k)
+        o.iterate(k)
+        xo, zo, yo = o.iterates()
+        assert rel(xg, xo) <= ITER_TOL and rel(zg, zo) <= ITER_TOL and rel(yg, yo) <= ITER_TOL, (name, k)
+    _node_chain(g, o, pr, A, l, u)
+
+
+@pytest.mark.parametrize("pers", [1, 2])
+@pytest.mark.parametrize("name", ["milp", "one_sided_rows", "A_1pct", "power_converter_K20"])
+def test_persistent_solver_on_structured_instances(oracle_mod, name, pers):
+    """the same instances once through the persistent streaming launch (product form; factor form with the tail as
+    S^-1): iterates and a chain of nodes against the oracle."""
+    pr = sp.make(name)
+    kw = dict(coop=0, resident=0, pers=pers)
+    if pers == 2:
+        kw["fold"] = 0
+    g, o, A, l, u = _pair(oracle_mod, pr, **kw)
+    n, M = A.shape[1], A.shape[0]
+    assert g.factor_stats()["pers"]
+    rng = np.random.RandomState(6)
+    x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(M)
+    for k in (1, 27):
+        g.warm_start(x=x0, y=y0)
+        o.warm_start(x=x0, y=y0)
+        xg, zg, yg = g.debug_iterate(k)
+        o.iterate(k)
+        xo, zo, yo = o.iterates()
+        assert rel(xg, xo) <= ITER_TOL and rel(zg, zo) <= ITER_TOL and rel(yg, yo) <= ITER_TOL, (name, k)
+    _node_chain(g, o, pr, A, l, u, depth=2)
+
+
+@pytest.mark.parametrize("name", ILL)
+def test_explicit_inverse_guard_falls_back_on_ill_conditioned_kkt(oracle_mod, name):
+    """P = 0 (or 1e-6 I) with fewer rows than variables: the residual of the explicit inverse measured at set-up is
+    above the threshold, the engine says so and iterates with the factor's sweeps -- and THAT matches the oracle."""
+    pr = sp.make(name)
+    g, o, A, l, u = _pair(oracle_mod, pr, coop=1, resident=0)
+    n, M = A.shape[1], A.shape[0]
+    fs = g.factor_stats()
+    res, tol, tripped = g.inverse_guard()
+    assert tripped and res > tol and not fs["coop"] and fs["inverse_guard_tripped"], (res, tol, fs)
+    rng = np.random.RandomState(7)
+    x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(M)
+    for k in (1, 27):
+        g.warm_start(x=x0, y=y0)
+        o.warm_start(x=x0, y=y0)
+        xg, zg, yg = g.debug_iterate(k)
+        o.iterate(k)
+        xo, zo, yo = o.iterates()
+        # (the conditioning that trips the guard also amplifies the summation-order differences of the sweeps: stated)
+        assert rel(xg, xo) <= 1e-6 and rel(zg, zo) <= 1e-6 and rel(yg, yo) <= 1e-6, (name, k)
+    g.warm_start(x=np.zeros(n), y=np.zeros(M))
+    o.warm_start(x=np.zeros(n), y=np.zeros(M))
+    rg, ro = g.solve(), o.solve()
+    assert rg.info.status_val == ro.info.status_val
+
+
+def test_guard_threshold_is_a_setting_and_small_problems_fall_back_too(oracle_mod, monkeypatch):
+    """MIOSQP_GUARD_TOL = 0 trips the guard on any problem: the cooperative range falls back to the launches, the
+    one-workgroup range (n + M <= 192) to the sweeps in LDS, whole trees to the workgroup kernel -- same answers."""
+    from miosqp_amd import bnb, qp
+    pr = problems.random_miqp(100, 150, 40, seed=7)
+    A, l, u = problems.extended(pr)
+    ref = qp.OSQP()
+    ref.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    assert ref.factor_stats()["coop"] and not ref.inverse_guard()[2]
+    monkeypatch.setenv("MIOSQP_GUARD_TOL", "0")
+    g = qp.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+    fs = g.factor_stats()
+    assert not fs["coop"] and fs["inverse_guard_tripped"] and g.inverse_guard()[2]
+    for s in (ref, g):
+        s.warm_start(x=np.zeros(100), y=np.zeros(A.shape[0]))
+    ra, rb = ref.solve(), g.solve()
+    assert (ra.info.status_val, ra.info.iter) == (rb.info.status_val, rb.info.iter)
+    assert rel(ra.x, rb.x) <= SOL_TOL
+    # one workgroup: whole tree with and without the explicit inverse
+    pr = problems.random_miqp(20, 30, 8, seed=3)
+    out = []
+    for tol in (None, "0"):
+        if tol is None:
+            monkeypatch.delenv("MIOSQP_GUARD_TOL")
+        else:
+            monkeypatch.setenv("MIOSQP_GUARD_TOL", tol)
+        m = bnb.MIOSQP()
+        m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+        assert m.work.solver.inverse_guard()[2] == (tol is not None)
+        r = m.solve()
+        out.append((r.status, r.upper_glob, np.round(r.x[pr["i_idx"]])))
+    assert out[0][0] == out[1][0] == bnb.MI_SOLVED
+    assert abs(out[0][1] - out[1][1]) <= 1e-6 * max(1.0, abs(out[0][1]))
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+def _engine(pr, **kw):
+    from miosqp_amd import qp
+    A, l, u = problems.extended(pr)
+    g = qp.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **dict(problems.QP_SETTINGS, **kw))
+    g.set_integer_rows(pr["i_idx"], pr["A"].shape[0])
+    g.set_root(l, u, 1e-3, 1e-3)
+    return g, A, l, u
+
+
+def test_whole_chip_launches_of_one_process_take_turns():
+    """Two engines whose kernels each need the whole chip (k_coop; kbp1), driven by two host threads that launch at
+    the same moment 1000 times: no launch is called off (before, two such launches could each hold part of the CUs
+    until one gave up after 100 ms), the answers are those of the engines alone."""
+    pr = problems.random_miqp(300, 500, 150, seed=2)
+    a, A, l, u = _engine(pr, coop=1, resident=0)
+    n, M = A.shape[1], A.shape[0]
+    rng = np.random.RandomState(0)
+    x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(M)
+    a.warm_start(x=x0, y=y0)
+    want = a.debug_iterate(20)
+    assert a.chip_turn_users() == 1
+    b, _, _, _ = _engine(pr, coop=1, resident=0)
+    assert a.chip_turn_users() == 2 and a.factor_stats()["coop"] and b.factor_stats()["coop"]
+    rounds = 1000
+    bar = threading.Barrier(2)
+    err = []
+
+    def coop_body(g):
+        try:
+            for k in range(rounds):
+                g.warm_start(x=x0, y=y0)
+                bar.wait()
+                got = g.debug_iterate(20)
+                if k % 100 == 0:
+                    for v, w in zip(got, want):
+                        np.testing.assert_array_equal(v, w)
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+            bar.abort()
+
+    ths = [threading.Thread(target=coop_body, args=(g,)) for g in (a, b)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not err, err
+    for g in (a, b):
+        fs = g.factor_stats()
+        assert fs["coop"] and fs["coop_fallbacks"] == 0
+    assert a.chip_turn_waits() > 0
+    # the batched persistent sweeps of two more engines against each other and against the cooperative launches
+    c, _, _, _ = _engine(pr, coop=0, resident=0, max_batch=256, batch_pers=1)
+    d, _, _, _ = _engine(pr, coop=0, resident=0, max_batch=256, batch_pers=1)
+    B = 256
+    L, U = np.tile(l, (B, 1)), np.tile(u, (B, 1))
+    X0, Y0 = np.zeros((B, n)), np.zeros((B, M))
+    for g in (c, d):
+        g.solve_batch(L, U, X0, Y0)
+        assert g.factor_stats()["batch_pers"]
+    bar = threading.Barrier(3)
+
+    def kbp_body(g):
+        try:
+            for _ in range(rounds):
+                bar.wait()
+                g.time_kernel(15, 25)
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+            bar.abort()
+
+    def coop_body2(g):
+        try:
+            for _ in range(rounds):
+                bar.wait()
+                g.debug_iterate(100)
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+            bar.abort()
+
+    ths = [threading.Thread(target=kbp_body, args=(c,)), threading.Thread(target=kbp_body, args=(d,)),
+           threading.Thread(target=coop_body2, args=(a,))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not err, err
+    assert c.call_off_word() == 0 and d.call_off_word() == 0
+    assert a.factor_stats()["coop_fallbacks"] == 0 and a.factor_stats()["coop"]
+    for g in (c, d):
+        assert g.batch_pers_fallbacks() == 0
+    b.close()
+    c.close()
+    d.close()
+    assert a.chip_turn_users() == 1
