@@ -140,8 +140,13 @@ struct Dev {
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
   int coop_dbg;                  // debug: 1 = no gather (ablation), 64 = workgroup 1 never starts (fault injection)
   int coop_nap;                  // 64-clock naps between publishing and the first poll of a round (calibrated)
-  int coop_stride;               // 8-byte words between the blocks of consecutive workgroups (>= 2 RW)
+  int coop_stride;               // 8-byte words between the blocks of consecutive workgroups (= 2 RW: entries are flat, 2 words each)
   size_t coop_half;              // words per parity
+  // the exchange's row layout (kernels_coop.inc "reduced indices"): W' = W without the identity (integer-bound) rows
+  const double *coop_W;          // NR x coop_ldw, NR = coop_mg + n  (== W, ldw while nothing is dropped)
+  int coop_ldw, coop_mg;         // coop_mg: general rows kept in W' (M while nothing is dropped)
+  const int *coop_brow;          // per variable: FULL index of its bound row, -1 without one (nullptr: none anywhere)
+  const double *coop_aj;         // per variable: scaled entry of its bound row, 0 without one
   // ---- batched mode: B nodes share the factor; vectors are [len][Bs], batch index fastest ----
   int Bs;  // column stride, multiple of 64
   double *b_l, *b_u, *b_x, *b_z, *b_y, *b_wh, *b_rx, *b_cv, *b_ut, *b_xt, *b_dx, *b_dy;
@@ -605,30 +610,31 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         HIPCHK(hipGetDevice(&dev_now));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, dev_now));
-        const int rw = 8;
+        // rows of W per workgroup: 16 halves the workgroups in the all-to-all (its cost grows with their number) for
+        // twice the products per thread; 8 only where 16 rows x the columns of a thread would not fit the registers
+        int rw = coop_pick_rw(N);
         if (const char *ev = getenv("MIOSQP_COOP_DBG")) d.coop_dbg = atoi(ev);
         const int T = (N + rw - 1) / rw;
         bool can = !e->resident && N <= 2048 && T <= prop.multiProcessorCount;
+        e->coop_cus = prop.multiProcessorCount;
         if (wantc && can) {
           // the grid must fit the device with one workgroup per CU: ask the runtime instead of assuming it
-          int per_cu = 0;
-          const hipError_t oq = N <= 1024
-              ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 2, true>, 512, 0)
-              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop<512, 8, 4, true>, 512, 0);
-          if (oq != hipSuccess || per_cu < 1) can = false;
+          if (coop_occupancy(rw, coop_pick_cpt(N), N <= 1024 ? 2 : 4) < 1) can = false;
         }
         if (wantc && can) {
           e->coop = true;
           e->coop_capable = true;
           e->coop_rw = rw;
-          e->coop_cpt = N <= 1024 ? 2 : 4;
+          e->coop_cpt = coop_pick_cpt(N);
+          e->coop_cptf = N <= 1024 ? 2 : 4;
           e->coop_T = T;
+          d.coop_mg = M;
           d.ldw = (N + 7) & ~7;
           double *Wd = nullptr;
           rc = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
           if (!rc) rc = dalloc(e, &d.coop_tag, 64);
           d.coop_stride = 2 * rw;
-          d.coop_half = (size_t)T * d.coop_stride;
+          d.coop_half = 2 * (size_t)((N + 15) & ~15);  // two words per entry, room for either row-block size
           if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_chk, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_q, (size_t)(256 + 16) * COOP_QS + 64);
@@ -637,10 +643,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           if (!rc) rc = dalloc(e, &d.coop_dec, 64);
           {
             // the test on workgroups of its own when the exchange grid leaves enough CUs free
-            const int spare = prop.multiProcessorCount - T;
-            int nt = spare >= 8 ? std::min(COOP_NT_MAX, spare) : 0;
-            if (const char *ev = getenv("MIOSQP_COOP_TESTERS")) nt = std::max(0, std::min(std::min(COOP_NT_MAX, spare), atoi(ev)));
-            d.coop_nt = nt;
+            d.coop_nt = coop_pick_testers(prop.multiProcessorCount - T);
             d.coop_lag = 12;
             if (const char *ev = getenv("MIOSQP_COOP_LAG")) d.coop_lag = std::max(1, atoi(ev));
           }
@@ -657,6 +660,8 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           }
           d.W = Wd;
           d.Kc = Kc;
+          d.coop_W = Wd;
+          d.coop_ldw = d.ldw;
           hipLaunchKernelGGL(k_build_kc, dim3((N + 255) / 256, N), dim3(256), 0, e->stream, d, Kc);
           // the explicit inverse is checked before it is used (kernels_guard.inc); when it fails this engine iterates
           // with the sweeps of the product form (two launches per iteration) instead
@@ -888,8 +893,10 @@ int miosqp_qp_set_integer_rows(miosqp_qp_engine *e, int32_t n_int, const int32_t
     }
   }
   // the captured graphs hold Dev by value but never read n_int / m_orig / i_idx contents
-  if (staged) return stage_mark(e, 1);
-  return 0;
+  if (staged) {
+    if (int rcm = stage_mark(e, 1)) return rcm;
+  }
+  return coop_drop_identity_rows(e, n_int, i_idx, m_orig);
 }
 
 int miosqp_qp_set_root(miosqp_qp_engine *e, const double *l_root, const double *u_root, double eps_int_feas,

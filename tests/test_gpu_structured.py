@@ -130,12 +130,16 @@ def test_explicit_inverse_guard_falls_back_on_ill_conditioned_kkt(oracle_mod, na
         xg, zg, yg = g.debug_iterate(k)
         o.iterate(k)
         xo, zo, yo = o.iterates()
-        # (the conditioning that trips the guard also amplifies the summation-order differences of the sweeps: stated)
-        assert rel(xg, xo) <= 1e-6 and rel(zg, zo) <= 1e-6 and rel(yg, yo) <= 1e-6, (name, k)
+        # Stated tolerance for these two instances: 1e-4 relative.  cond(K) ~ 1e8 amplifies the summation-order
+        # differences between ANY two implementations alike -- measured on MI355X (tools/probes/structured_probe.py,
+        # profiles/r04_structured_probe.json): explicit inverse, product-form launches and persistent sweeps are all
+        # 2e-6 .. 1.2e-5 from the oracle after 27-75 iterations (iterates of magnitude 1e7: the relaxation is
+        # unbounded), and 1e-12 on every other instance.
+        assert rel(xg, xo) <= 1e-4 and rel(zg, zo) <= 1e-4 and rel(yg, yo) <= 1e-4, (name, k)
     g.warm_start(x=np.zeros(n), y=np.zeros(M))
     o.warm_start(x=np.zeros(n), y=np.zeros(M))
     rg, ro = g.solve(), o.solve()
-    assert rg.info.status_val == ro.info.status_val
+    assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter)
 
 
 def test_guard_threshold_is_a_setting_and_small_problems_fall_back_too(oracle_mod, monkeypatch):
