@@ -610,9 +610,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         HIPCHK(hipGetDevice(&dev_now));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, dev_now));
-        // rows of W per workgroup: 16 halves the workgroups in the all-to-all (its cost grows with their number) for
-        // twice the products per thread; 8 only where 16 rows x the columns of a thread would not fit the registers
-        int rw = coop_pick_rw(N);
+        int rw = coop_pick_rw(N);  // rows of W per workgroup
         if (const char *ev = getenv("MIOSQP_COOP_DBG")) d.coop_dbg = atoi(ev);
         const int T = (N + rw - 1) / rw;
         bool can = !e->resident && N <= 2048 && T <= prop.multiProcessorCount;

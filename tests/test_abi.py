@@ -83,4 +83,4 @@ def test_cooperative_exchange_loop_has_no_register_spills():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_coop_isa.py")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("scratch accesses 0") >= 7  # every instantiation with testers
+    assert r.stdout.count("scratch accesses 0") >= 4  # every instantiation with testers

@@ -21,8 +21,7 @@ pr = problems.random_miqp(n, m, p, seed=0)
 A, l, u = problems.extended(pr)
 M = A.shape[0]
 for name, env in (("full layout, 8 rows", {"MIOSQP_COOP_IDROWS": "0", "MIOSQP_COOP_RW": "8"}),
-                  ("reduced, 8 rows", {"MIOSQP_COOP_RW": "8"}), ("reduced, 16 rows", {"MIOSQP_COOP_RW": "16"}),
-                  ("reduced, default", {})):
+                  ("reduced, 8 rows", {})):
     for k, v in env.items():
         os.environ[k] = v
     g = qp.OSQP()
