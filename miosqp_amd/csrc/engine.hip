@@ -185,6 +185,32 @@ struct Dev {
   double *c_pri, *c_dua, *c_obj, *c_lower;
 };
 
+struct SearchDigest {  // coherent host memory
+  int status, iter, int_inf, nextvar, action, branched, pad;
+  int todo;  // 1: the launch only ran the relaxation (or was called off): the host still has to launch the epilogue kernels
+  double lower, heur_viol, heur_obj, pri_res, dua_res, obj_val;
+  unsigned long long seq;  // written last (release, system scope): the record of node `seq` is complete
+};
+struct SearchArgs {
+  const double *lo_s, *hi_s;  // this node's integer-row bounds
+  const double *x_w, *y_w;    // its warm start: the parent's solution
+  double *x_s, *y_s;          // where its own solution goes
+  double *lo0, *hi0, *lo1, *hi1;  // the children's bounds (slots reserved by the host)
+  double *inc_x;              // the incumbent
+  double upper;               // the incumbent's value as the host knows it
+  SearchDigest *dg;
+  unsigned long long seq;
+};
+
+// node mode of k_coop (hosted search, host_search.inc): prologue and epilogue of a node inside the cooperative launch
+struct CoopNode {
+  int on;            // 0: plain solve -- iterates in d.*, prologue / epilogue by the host's kernels
+  int epi;           // 1: the tester workgroups run the epilogue (unscale, clamp, digest, heuristic, objective, commit)
+  int tpr_h, tpr_o;  // threads per row of the sparse rows of Abar / of the unscaled P, as the launches use them
+  SearchArgs a;
+  unsigned long long *epi_buf;  // exchange buffer of the epilogue: 2 n + COOP_NT_MAX tagged entries
+};
+
 // The device code and the host driver live in the .inc files below: ONE translation unit (everything
 // sits in the same anonymous namespace and the kernels are templates instantiated by the host code),
 // split only for reading.
@@ -300,6 +326,8 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->search) {
     NodeSearch *S = static_cast<NodeSearch *>(e->search);
     if (S->dg) hipHostFree(S->dg);
+    for (hipEvent_t ev : S->ev)
+      if (ev) hipEventDestroy(ev);
     delete S;
   }
   if (e->h_ready) hipHostFree(e->h_ready);
@@ -639,6 +667,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           if (!rc) rc = dalloc(e, &d.coop_reg, 128);
           if (!rc) rc = dalloc(e, &d.coop_chz, d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_dec, 64);
+          if (!rc) rc = dalloc(e, &e->coop_epi, 2 * (size_t)(2 * 1024 + COOP_NT_MAX) + 64);
           {
             // the test on workgroups of its own when the exchange grid leaves enough CUs free
             d.coop_nt = coop_pick_testers(prop.multiProcessorCount - T);

@@ -21,7 +21,9 @@ pr = problems.random_miqp(n, m, p, seed=0)
 A, l, u = problems.extended(pr)
 M = A.shape[0]
 for name, env in (("full layout, 8 rows", {"MIOSQP_COOP_IDROWS": "0", "MIOSQP_COOP_RW": "8"}),
-                  ("reduced, 8 rows", {})):
+                  ("reduced, launches per node", {"MIOSQP_COOP_NODE": "0"}),
+                  ("reduced, prologue in", {"MIOSQP_COOP_EPI": "0"}),
+                  ("reduced, one launch", {})):
     for k, v in env.items():
         os.environ[k] = v
     g = qp.OSQP()
@@ -62,7 +64,7 @@ for name, env in (("full layout, 8 rows", {"MIOSQP_COOP_IDROWS": "0", "MIOSQP_CO
         rec = (di / dt, dn / dt, 1e6 * dt / dn, di / dn)
         if best is None or rec[0] > best[0]:
             best = rec
-    print("%-22s coop %s nap %2d: %.3f us/iter back to back | hosted: %.0f it/s  %.1f nodes/s  %.1f us/node  %.1f it/node"
+    print("%-28s coop %s nap %2d: %.3f us/iter back to back | hosted: %.0f it/s  %.1f nodes/s  %.1f us/node  %.1f it/node"
           % (name, fs["coop"], fs["coop_nap"], us, best[0], best[1], best[2], best[3]), flush=True)
     mm.work.solver.close()
     for k in env:
