@@ -208,7 +208,8 @@ struct CoopNode {
   int epi;           // 1: the tester workgroups run the epilogue (unscale, clamp, digest, heuristic, objective, commit)
   int tpr_h, tpr_o;  // threads per row of the sparse rows of Abar / of the unscaled P, as the launches use them
   SearchArgs a;
-  unsigned long long *epi_buf;  // exchange buffer of the epilogue: 2 n + COOP_NT_MAX tagged entries
+  unsigned long long *epi_buf;  // exchange buffer of the epilogue: 2 n + (workgroups of the launch) tagged entries
+  unsigned long long *stamps;   // debug (MIOSQP_SEARCH_STAMPS=1): 16 wall-clock stamps (100 MHz) of this node, or nullptr
 };
 
 // The device code and the host driver live in the .inc files below: ONE translation unit (everything
@@ -667,11 +668,14 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           if (!rc) rc = dalloc(e, &d.coop_reg, 128);
           if (!rc) rc = dalloc(e, &d.coop_chz, d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_dec, 64);
-          if (!rc) rc = dalloc(e, &e->coop_epi, 2 * (size_t)(2 * 1024 + COOP_NT_MAX) + 64);
+          if (!rc) rc = dalloc(e, &e->coop_epi, 2 * (size_t)(2 * 1024 + 256) + 64);
           {
             // the test on workgroups of its own when the exchange grid leaves enough CUs free
             d.coop_nt = coop_pick_testers(prop.multiProcessorCount - T);
-            d.coop_lag = 12;
+            // iterations between a test and the point where the grid waits for its decision: the testers need ~27 us at
+            // config 2 (operands 3, rows 17-20, reduction and decision 5), an iteration takes 1.9: at 12 the grid stood
+            // still for ~5 us at every test (438 k it/s in the hosted search), at 14 / 16 / 18: 458 / 461 / 460 k (r04)
+            d.coop_lag = 16;
             if (const char *ev = getenv("MIOSQP_COOP_LAG")) d.coop_lag = std::max(1, atoi(ev));
           }
           double *Kc = nullptr;
