@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 KERNELS = ["k_panel_fwd", "k_tail_fwd", "k_tail_bwd", "k_panel_bwd"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-ALL_LEGS = ("batched", "stream", "config5", "config4", "config1", "cpu", "pyloop")
+ALL_LEGS = ("batched", "stream", "config5", "config4", "config1", "cpu", "pyloop", "rho_auto")
 
 
 def pmc_traffic(kernel, tag=""):
@@ -400,6 +400,66 @@ def cpu_baseline(prob, budget_s):
                        % (srch.nodes, srch.iters, dt, info["nproc"] or 0, what))
 
 
+def rho_auto_leg(prob, cfg, seed, local_rank, nodes):
+    """The headline workload with rho chosen ONCE per MIQP at setup (qp setting rho="auto": OSQP's own update rule applied
+    to the root's iterates, then frozen -- one factor for every node as before) next to the frozen default rho = 0.1 of
+    `value`.  The reference passes only eps_* to osqp.setup (/root/reference/miosqp/workspace.py:67-68), i.e. OSQP's
+    defaults, which adapt rho.  Same MIQP stream as the headline (same seed); hosted node-at-a-time search."""
+    import torch
+    from miosqp_amd import bnb, problems, search
+    t0 = time.perf_counter()
+    model = bnb.MIOSQP()
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=10 ** 9)
+    model.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"], prob["i_u"], st,
+                dict(problems.QP_SETTINGS, device=local_rank, rho="auto"))
+    t_setup = time.perf_counter() - t0
+    eng = model.work.solver
+    hs = search.HostedSearch(model)
+    rng = np.random.RandomState(seed + 12345)
+    m_orig = cfg["m"]
+
+    def reroot():
+        model.update_vectors(q=rng.randn(cfg["n"]), l=-2 + rng.rand(m_orig), u=2 + rng.rand(m_orig))
+        hs.begin_instance()
+
+    # one whole tree (the seed's own MIQP), timed from its root
+    torch.cuda.synchronize()
+    tt = time.perf_counter()
+    n0, i0 = hs.nodes, hs.iters
+    alive = 1
+    while alive != 0 and time.perf_counter() - tt < 20.0:
+        alive = hs.step(256)
+    torch.cuda.synchronize()
+    tree = dict(ms_to_close=round(1e3 * (time.perf_counter() - tt), 3), nodes=hs.nodes - n0, iters=hs.iters - i0,
+                closed=bool(alive == 0), upper_glob=float(model.work.upper_glob))
+    # the rate over `nodes` node relaxations of the MIQP stream
+    reroot()
+    left = 20
+    while left > 0:
+        b = hs.nodes
+        if hs.step(left) == 0:
+            reroot()
+        left -= max(1, hs.nodes - b)
+    torch.cuda.synchronize()
+    n0, i0 = hs.nodes, hs.iters
+    t1 = time.perf_counter()
+    left = nodes
+    while left > 0:
+        b = hs.nodes
+        if hs.step(left) == 0:
+            reroot()
+        left -= max(1, hs.nodes - b)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    dn, di = hs.nodes - n0, hs.iters - i0
+    out = dict(what="the headline's search with rho chosen once at setup (rho=\"auto\"), then frozen; opt-in",
+               rho=eng.rho(), rho_default=0.1, setup_s=round(t_setup, 3), nodes=dn, value=round(di / dt, 1),
+               unit="ADMM iter/s", nodes_per_s=round(dn / dt, 2), iters_per_node=round(di / max(1, dn), 1),
+               ms_per_node=round(1e3 * dt / max(1, dn), 4), one_tree=tree)
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -434,7 +494,7 @@ def main():
                     help="skip the back-to-back kernel timing launches (profiling runs: every dispatch of the hot "
                          "kernel is then a node relaxation of the timed workload)")
     ap.add_argument("--legs", default="all",
-                    help="comma list of extra legs to run: batched,stream,config5,config4,config1,cpu ('none' = headline only)")
+                    help="comma list of extra legs to run: batched,stream,config5,config4,config1,cpu,pyloop,rho_auto ('none' = headline only)")
     args = ap.parse_args()
     legs = set(ALL_LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
     if args.no_cpu_baseline:
@@ -914,6 +974,8 @@ def main():
                 out["config4"] = mpc_leg(local_rank)
             if "config1" in legs:
                 out["config1"] = small_leg(args.seed, local_rank)
+            if "rho_auto" in legs and hosted:
+                out["rho_auto"] = rho_auto_leg(prob, cfg, args.seed, local_rank, max(150, args.steps))
         if world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
         print(json.dumps(out))

@@ -84,6 +84,15 @@ typedef struct miosqp_qp_settings {
                                 registers and LDS of 256 co-resident workgroups (n <= 512, rows in the products <= 1024;
                                 auto: n >= 256).  Called off -- the chunk goes through two launches per iteration
                                 instead -- when the device is shared and the workgroups are not co-resident in time */
+  int32_t rho_auto;          /* 0 (default): `rho` as given.  1: rho is chosen ONCE per problem at setup and then frozen
+                                (opt-in; Python: rho="auto").  The reference hands only eps_* to osqp.setup
+                                (/root/reference/miosqp/workspace.py:67-68, examples/random_miqp/run_example.py:113-116),
+                                i.e. OSQP's defaults, which adapt rho while solving; here one factor serves every node of
+                                a tree, so OSQP's update rule -- rho <- rho sqrt(normalised primal residual / normalised
+                                dual residual), scaled quantities, clamped to [1e-6, 1e6] -- is applied once, to the
+                                iterates 50 iterations from zero on the setup's bounds, rounded to two significant
+                                digits, and the KKT matrix is factorised for that value.  Config 2: 0.1 -> 0.013,
+                                a third of the iterations per node.  miosqp_qp_get_rho reports the value in use */
 } miosqp_qp_settings;
 
 /* What the reference reads from `results.info` (/root/reference/miosqp/node.py:111-125) plus
@@ -308,6 +317,9 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
  * the cooperative form; out[7] bit 17 = the explicit KKT inverse failed its residual check at set-up and the engine
  * iterates with the factor's sweeps instead (see miosqp_qp_get_inverse_guard).  out must hold 10 values. */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
+
+/* rho in use (differs from settings.rho when settings.rho_auto chose it) */
+int miosqp_qp_get_rho(miosqp_qp_engine *e, double *rho);
 
 /* The register-resident solvers iterate on the explicit inverse of the scaled KKT matrix (sigma = 1e-6), which -- unlike
  * the sweeps with the LDL^T factor the reference's linear solver performs at /root/reference/miosqp/workspace.py:63-68

@@ -18,7 +18,8 @@ class Settings(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf", "eps_dual_inf")] + \
                [(k, C.c_int32) for k in ("max_iter", "scaling", "check_termination", "warm_start",
-                                         "device", "max_batch", "fold", "resident", "setup_on_device", "coop", "pers", "batch_pers")]
+                                         "device", "max_batch", "fold", "resident", "setup_on_device", "coop", "pers", "batch_pers",
+                                         "rho_auto")]
 
 
 class Info(C.Structure):
@@ -101,6 +102,7 @@ SYMBOLS = {
     "miosqp_qp_get_scaling": (C.c_int, [C.c_void_p, dp, dp, dp]),
     "miosqp_qp_get_factor_stats": (C.c_int, [C.c_void_p, i64p]),
     "miosqp_qp_get_inverse_guard": (C.c_int, [C.c_void_p, dp]),
+    "miosqp_qp_get_rho": (C.c_int, [C.c_void_p, dp]),
     "miosqp_qp_get_loop_stats": (C.c_int, [C.c_void_p, dp, i64p, C.c_int32]),
     "miosqp_qp_get_batch_stats": (C.c_int, [C.c_void_p, dp, i64p, i64p, C.c_int32]),
     "miosqp_qp_debug_counter": (C.c_int64, [C.c_void_p, C.c_int32]),

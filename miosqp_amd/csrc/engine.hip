@@ -352,12 +352,77 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
 static int stage_wait(miosqp_qp_engine *e, int k);
 static int stage_mark(miosqp_qp_engine *e, int k);
 
+// rho chosen once per problem (settings.rho_auto): OSQP's update rule on the scaled iterates after RHO_ONCE_ITERS
+// iterations from zero, rounded to two significant digits -- the arithmetic of oracle/qp_oracle.c's rho_estimate, loop
+// for loop, on the host's copy of the scaled matrices (the iterates come from the device).
+constexpr int RHO_ONCE_ITERS = 50;
+static double rho_round2(double r) {
+  if (!(r > 0)) return r;
+  const double e = floor(log10(r)), p = pow(10.0, e);
+  return floor(r / p * 10.0 + 0.5) / 10.0 * p;
+}
+static double rho_estimate_host(const miosqp::Scaled &sc, double rho, const double *x, const double *z, const double *y) {
+  const int n = sc.n, M = sc.M;
+  std::vector<double> Ax(M, 0.0), Px(n, 0.0), Aty(n, 0.0);
+  for (int j = 0; j < n; j++)
+    for (int p = sc.Ap[j]; p < sc.Ap[j + 1]; p++) Ax[sc.Ai[p]] += sc.Ax[p] * x[j];
+  for (int j = 0; j < n; j++)
+    for (int p = sc.Pp[j]; p < sc.Pp[j + 1]; p++) {
+      const int i = sc.Pi[p];
+      Px[i] += sc.Px[p] * x[j];
+      if (i != j) Px[j] += sc.Px[p] * x[i];
+    }
+  for (int j = 0; j < n; j++) {
+    double t = 0;
+    for (int p = sc.Ap[j]; p < sc.Ap[j + 1]; p++) t += sc.Ax[p] * y[sc.Ai[p]];
+    Aty[j] = t;
+  }
+  auto ninf = [](const double *v, int k) { double r = 0; for (int i = 0; i < k; i++) r = fmax(r, fabs(v[i])); return r; };
+  double pri = 0, dua = 0;
+  for (int i = 0; i < M; i++) pri = fmax(pri, fabs(Ax[i] - z[i]));
+  for (int j = 0; j < n; j++) dua = fmax(dua, fabs(Px[j] + sc.q[j] + Aty[j]));
+  const double pn = fmax(ninf(z, M), ninf(Ax.data(), M));
+  const double dn = fmax(ninf(sc.q.data(), n), fmax(ninf(Aty.data(), n), ninf(Px.data(), n)));
+  pri /= (pn + 1e-10);
+  dua /= (dn + 1e-10);
+  double r = rho * sqrt(pri / (dua + 1e-10));
+  r = fmin(fmax(r, 1e-6), 1e6);
+  return rho_round2(r);
+}
+
 int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t *Pp, const int32_t *Pi,
                     const double *Px, const int32_t *Ap, const int32_t *Ai, const double *Ax,
                     const double *q, const double *l, const double *u, const miosqp_qp_settings *s) {
   if (!out || n <= 0 || M < 0 || !Pp || !Ap || !q || !s || (M > 0 && (!l || !u))) {
     g_err = "setup: bad argument";
     return MIOSQP_EARG;
+  }
+  if (s->rho_auto && M > 0) {
+    // a throw-away engine in the plain multi-kernel form for the probing iterations, then the real one at the chosen
+    // rho (the equilibration does not depend on rho and is simply repeated: set-up runs once per MIQP)
+    miosqp_qp_settings s1 = *s;
+    s1.rho_auto = 0;
+    miosqp_qp_settings sp = s1;
+    sp.coop = 0;
+    sp.pers = 0;
+    sp.max_batch = 1;
+    miosqp_qp_engine *probe = nullptr;
+    int rc = miosqp_qp_setup(&probe, n, M, Pp, Pi, Px, Ap, Ai, Ax, q, l, u, &sp);
+    if (rc) return rc;
+    std::vector<double> xs(n), zs(M), ys(M);
+    {
+      const int big = n > M ? n : M;
+      hipLaunchKernelGGL(k_zero_iterates, dim3((big + 255) / 256), dim3(256), 0, probe->stream, probe->d);
+    }
+    rc = miosqp_qp_debug_iterate(probe, RHO_ONCE_ITERS, xs.data(), zs.data(), ys.data());
+    double rho_new = s1.rho;
+    if (!rc) rho_new = rho_estimate_host(probe->sc, s1.rho, xs.data(), zs.data(), ys.data());
+    miosqp_qp_cleanup(probe);
+    if (rc) return rc;
+    if (rho_new > 0) s1.rho = rho_new;
+    rc = miosqp_qp_setup(out, n, M, Pp, Pi, Px, Ap, Ai, Ax, q, l, u, &s1);
+    if (!rc) (*out)->st.rho_auto = 1;
+    return rc;
   }
   if (M == 0) {
     // miOSQP always has rows: data.py:5-33 appends one identity row per integer variable
@@ -1451,6 +1516,12 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0) |
            (e->pers ? 16 : 0) | ((e->pers && e->pp.sinv) ? 32 : 0) | ((e->pers && e->pp.small) ? 64 : 0) |
            ((e->d.coop_nap & 0xff) << 8) | (e->kbp ? (1 << 16) : 0) | (e->guard_tripped ? (1 << 17) : 0);
+  return 0;
+}
+
+int miosqp_qp_get_rho(miosqp_qp_engine *e, double *rho) {
+  if (!e || !rho) return MIOSQP_EARG;
+  *rho = e->d.rho;
   return 0;
 }
 

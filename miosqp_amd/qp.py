@@ -54,6 +54,11 @@ def _settings_from_kwargs(kw):
                 raise ValueError("adaptive_rho is not supported: rho is one fixed scalar so that "
                                  "the KKT factor is shared by every node (DESIGN.md)")
             continue
+        if k == "rho" and isinstance(v, str):
+            if v != "auto":
+                raise ValueError("rho: a number or 'auto'")
+            s.rho_auto = 1  # chosen once at setup (miosqp_qp_settings.rho_auto), from the default starting value
+            continue
         if k not in dict(s._fields_) or k == "reserved":
             raise TypeError("setup() got an unexpected setting %r" % k)
         setattr(s, k, v)
@@ -398,6 +403,12 @@ class OSQP(object):
                     tpr=(int(out[4]), int(out[5]), int(out[6])),
                     fold=bool(out[7] & 1), resident=bool(out[7] & 2), setup_on_device=bool(out[7] & 4), coop=bool(out[7] & 8), pers=bool(out[7] & 16), tail_inverse=bool(out[7] & 32), pers_small=bool(out[7] & 64), coop_nap=(out[7] >> 8) & 0xff,
                     batch_pers=bool(out[7] & (1 << 16)), inverse_guard_tripped=bool(out[7] & (1 << 17)))
+
+    def rho(self):
+        """the rho in use (differs from the setting after rho="auto")"""
+        out = np.zeros(1)
+        _check(self._lib.miosqp_qp_get_rho(self._h, out.ctypes.data_as(_lib.dp)), "get_rho")
+        return float(out[0])
 
     def inverse_guard(self):
         """(residual, threshold, tripped) of the set-up check of the explicit KKT inverse; residual -1: none was built."""

@@ -20,7 +20,7 @@ _LIB = None
 class Settings(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf", "eps_dual_inf")] + \
-               [(k, C.c_int) for k in ("max_iter", "scaling", "check_termination", "warm_start")]
+               [(k, C.c_int) for k in ("max_iter", "scaling", "check_termination", "warm_start", "rho_auto")]
 
 
 class Info(C.Structure):
@@ -52,6 +52,8 @@ def lib():
         L.oqp_get_iterates.argtypes = [vp, dp, dp, dp]
         L.oqp_get_scaling.argtypes = [vp, dp, dp, dp]
         L.oqp_factor_nnz.argtypes = [vp]
+        L.oqp_get_rho.argtypes = [vp]
+        L.oqp_get_rho.restype = C.c_double
         L.oqp_cleanup.argtypes = [vp]
         L.oqp_cleanup.restype = None
         L.oqp_constant.argtypes = [C.c_char_p]
@@ -84,6 +86,11 @@ def make_settings(kw):
         if k == "adaptive_rho" and v:
             raise ValueError("adaptive_rho is not part of the frozen spec (DESIGN.md)")
         if k in _IGNORED:
+            continue
+        if k == "rho" and isinstance(v, str):
+            if v != "auto":
+                raise ValueError("rho: a number or 'auto'")
+            s.rho_auto = 1  # chosen once at setup from the default starting value, then frozen
             continue
         if not hasattr(s, k):
             raise TypeError("unknown setting %r" % k)
@@ -154,6 +161,10 @@ class OSQP(object):
 
     def factor_nnz(self):
         return lib().oqp_factor_nnz(self._h)
+
+    def rho(self):
+        """the rho in use (differs from the setting after rho="auto")"""
+        return lib().oqp_get_rho(self._h)
 
     def __del__(self):
         if self._h and _LIB is not None:
