@@ -25,6 +25,7 @@ def main():
         A, l, u = problems.extended(pr)
         g = qp.OSQP()
         g.setup(pr["P"], pr["q"], A, l, u, coop=1, resident=0, **problems.QP_SETTINGS)
+        g.set_integer_rows(pr["i_idx"], m)  # (the exchange without the identity rows: its own grid, its own entry)
         fs = g.factor_stats()
         print("N %d T %d coop %s nap %d" % (N, (N + 7) // 8, fs["coop"], fs["coop_nap"]), flush=True)
         g.close()

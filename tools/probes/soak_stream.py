@@ -34,7 +34,8 @@ while time.time() - t0 < budget:
     trees += 1
     model.update_vectors(q=rng.randn(cfg["n"]), l=-2 + rng.rand(cfg["m"]), u=2 + rng.rand(cfg["m"]))
     ns.begin_instance()
-print("one pool: %d trees, %d nodes, %.1f s" % (trees, ns.nodes, time.time() - t0))
+print("one pool: %d trees, %d nodes, %.1f s, persistent launches called off %d" %
+      (trees, ns.nodes, time.time() - t0, model.work.solver.batch_pers_fallbacks()))
 model.work.solver.close()
 
 mp = stream.MultiPoolSearch(make, pools=2, columns=256, exchange_every=4, driver="native")
@@ -45,4 +46,7 @@ while time.time() - t0 < budget:
     assert all(len(sh.ss.free) == sh.ss.capacity for sh in mp.sh) or r.status != bnb.MI_SOLVED
     trees += 1
     mp.update_vectors(q=rng.randn(cfg["n"]), l=-2 + rng.rand(cfg["m"]), u=2 + rng.rand(cfg["m"]))
-print("two pools: %d trees, %d nodes, %.1f s" % (trees, sum(sh.ss.nodes for sh in mp.sh), time.time() - t0))
+fb = [m.work.solver.batch_pers_fallbacks() for m in mp.models]
+print("two pools: %d trees, %d nodes, %.1f s, persistent launches called off %s, whole-chip launches that took turns %d" %
+      (trees, sum(sh.ss.nodes for sh in mp.sh), time.time() - t0, fb, mp.models[0].work.solver.chip_turn_waits()))
+assert sum(fb) == 0, fb

@@ -2,7 +2,7 @@
 # Writes gpurun_out/<tag>/...; the summaries worth keeping are copied into profiles/ (committed) by hand.
 # Counters are collected in their own passes (--kernel-trace + --pmc only), as the pool requires.
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 ONLY=${2:-}   # optional: one of default nodes_only persistent two_kernel_form cfg5 cfg5x batched all_legs (everything when empty)
 want() { [ -z "$ONLY" ] || [ "$ONLY" = "$1" ]; }
 cd $GRAFT_REPO_ROOT
@@ -43,9 +43,7 @@ fi
 
 # 3. node launches only: every k_coop dispatch is one node relaxation of the timed workload
 if want nodes_only; then
-export MIOSQP_COOP_NAP=18
-prof nodes_only "--steps 150 --warmup 10 --legs none --no-probes" "MIOSQP_COOP_NAP=18"
-unset MIOSQP_COOP_NAP
+prof nodes_only "--steps 150 --warmup 10 --legs none --no-probes" ""
 fi
 
 # 4. the streaming forms of the same workload: persistent (one launch per node) and two launches per iteration
@@ -80,7 +78,8 @@ fi
 # 7. the batched leg alone (config 3: waves, then the stream on the leaf pool)
 if want batched; then
 export MIOSQP_POOL_NOGRAPH=1
-prof batched "--steps 20 --warmup 5 --legs batched --no-probes" "MIOSQP_POOL_NOGRAPH=1"
+# ONE pool only (--pools 1): with the two-pool leg in the same table the test kernels' maxima are contention, not the kernel
+prof batched "--steps 20 --warmup 5 --legs batched --no-probes --pools 1" "MIOSQP_POOL_NOGRAPH=1"
 unset MIOSQP_POOL_NOGRAPH
 fi
 ls -la $O
