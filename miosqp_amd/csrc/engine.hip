@@ -137,6 +137,7 @@ struct Dev {
   unsigned long long *coop_dec;  // the testers' decision {status | tag}
   int coop_nt;                   // tester workgroups behind the exchange grid (0: the test runs inside the grid)
   int coop_lag;                  // iterations between a test and the point where the grid waits for its decision
+  int coop_tres;                 // the testers keep their rows of Kc in registers (kernels_coop.inc: coop_tester<.., RES>)
   const double *Kc;              // [ 0 Abar ; Abar^T Pbar ], N x ldw
   int coop_dbg;                  // debug: 1 = no gather (ablation), 64 = workgroup 1 never starts (fault injection)
   int coop_nap;                  // 64-clock naps between publishing and the first poll of a round (calibrated)
@@ -737,11 +738,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           {
             // the test on workgroups of its own when the exchange grid leaves enough CUs free
             d.coop_nt = coop_pick_testers(prop.multiProcessorCount - T);
-            // iterations between a test and the point where the grid waits for its decision: the testers need ~27 us at
-            // config 2 (operands 3, rows 17-20, reduction and decision 5), an iteration takes 1.9: at 12 the grid stood
-            // still for ~5 us at every test (438 k it/s in the hosted search), at 14 / 16 / 18: 458 / 461 / 460 k (r04)
-            d.coop_lag = 16;
-            if (const char *ev = getenv("MIOSQP_COOP_LAG")) d.coop_lag = std::max(1, atoi(ev));
+            coop_pick_lag(e);
           }
           double *Kc = nullptr;
           if (!rc) rc = dalloc(e, &Kc, (size_t)N * d.ldw + 64);

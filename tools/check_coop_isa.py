@@ -32,7 +32,18 @@ def loops(asm):
         # from the loop header to the end of the poll loop that follows the nap
         end = sleeps[1] + 60 if len(sleeps) > 1 else sleeps[0] + 300
         body = F[h:end]
-        out.append((name, len(body), sum("scratch_" in l for l in body), sum("v_readlane" in l for l in body)))
+        # THE invariant: between a poll load (global_load_dwordx4 ... sc1, inline asm) and the s_waitcnt vmcnt(0) that
+        # follows it, no scratch access -- a spill there would store a register whose data has not arrived
+        hazard, open_poll = 0, False
+        for l in body:
+            c = l.split(";")[0]
+            if "global_load_dwordx4" in c and "sc1" in c:
+                open_poll = True
+            elif "s_waitcnt" in c and "vmcnt(0)" in c:
+                open_poll = False
+            elif open_poll and "scratch_" in c:
+                hazard += 1
+        out.append((name, len(body), sum("scratch_" in l for l in body), sum("v_readlane" in l for l in body), hazard))
     return out
 
 
@@ -44,12 +55,12 @@ def main():
                                "--cuda-device-only", "-w", "engine.hip", "-o", asm], cwd=src)
         res = loops(open(asm).read())
     bad = 0
-    for name, lines, scratch, readlane in res:
-        print("%s: exchange loop %d lines, scratch accesses %d, v_readlane %d" % (name, lines, scratch, readlane))
-        # the instantiations with testers (...Lb1E) poll with separate loads and wait: their loop must be spill-free;
-        # the others (in-grid test) issue loads and wait as one asm statement, a spill there only costs time
-        if "Lb1EEE" in name:
-            bad += scratch
+    for name, lines, scratch, readlane, hazard in res:
+        print("%s: exchange loop %d lines, scratch accesses %d, v_readlane %d, scratch accesses between a poll and its wait %d"
+              % (name, lines, scratch, readlane, hazard))
+        bad += hazard
+        # (scratch accesses elsewhere in the loop cost time, not correctness: reported, and kept at zero for the layout of the
+        #  headline -- 3 columns per thread, testers -- by tests/test_abi.py)
     if not res:
         print("no k_coop instantiation found")
         return 1
