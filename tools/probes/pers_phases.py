@@ -1,5 +1,5 @@
 """Phase clocks of the persistent streaming solver (k_pers): shader clocks of thread 0 of every workgroup, per iteration.
-usage: python tools/probes/pers_phases.py n m p density fold"""
+usage: python tools/probes/pers_phases.py n m p density fold [pers]"""
 import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from miosqp_amd import qp, problems, _lib
@@ -7,9 +7,10 @@ a = sys.argv[1:]
 n, m, p = (int(a[0]), int(a[1]), int(a[2])) if len(a) >= 3 else (500, 1000, 250)
 dens = float(a[3]) if len(a) > 3 else 0.7
 fold = int(a[4]) if len(a) > 4 else 1
+pers = int(a[5]) if len(a) > 5 else 1
 pr = problems.random_miqp(n, m, p, density=dens, seed=0)
 A, l, u = problems.extended(pr)
-g = qp.OSQP(); g.setup(pr['P'], pr['q'], A, l, u, fold=fold, coop=0, resident=0, pers=1, **problems.QP_SETTINGS)
+g = qp.OSQP(); g.setup(pr['P'], pr['q'], A, l, u, fold=fold, coop=0, resident=0, pers=pers, **problems.QP_SETTINGS)
 assert g.factor_stats()["pers"]
 g.warm_start(x=np.zeros(n), y=np.zeros(A.shape[0]))
 lib = _lib.load()
