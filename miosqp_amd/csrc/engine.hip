@@ -354,8 +354,9 @@ static int stage_wait(miosqp_qp_engine *e, int k);
 static int stage_mark(miosqp_qp_engine *e, int k);
 
 // rho chosen once per problem (settings.rho_auto): OSQP's update rule on the scaled iterates after RHO_ONCE_ITERS
-// iterations from zero, rounded to two significant digits -- the arithmetic of oracle/qp_oracle.c's rho_estimate, loop
-// for loop, on the host's copy of the scaled matrices (the iterates come from the device).
+// iterations from zero, rounded to two significant digits -- loop for loop the arithmetic the CPU restatement under the
+// tests uses for the same setting (its rho_estimate), on the host's copy of the scaled matrices (the iterates come from
+// the device).
 constexpr int RHO_ONCE_ITERS = 50;
 static double rho_round2(double r) {
   if (!(r > 0)) return r;

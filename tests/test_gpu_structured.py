@@ -180,6 +180,46 @@ def test_guard_threshold_is_a_setting_and_small_problems_fall_back_too(oracle_mo
     np.testing.assert_array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("name", ["milp", "equality_rows", "one_sided_rows", "A_5pct", "badly_scaled", "power_converter_K10",
+                                  "power_converter_K20"])
+def test_hosted_search_on_structured_instances(name, monkeypatch):
+    """The node of the hosted search as ONE launch (k_coop's node mode: prologue by the owners, epilogue -- clamp, digest,
+    rounding heuristic, objective, children, incumbent -- on the chip; workspace.py:282-334, node.py:96-143) on matrices
+    that are not random-dense: the first 40 nodes of the tree, against the Python loop that drives solve_node and against
+    the same search with the epilogue in the host's kernels (MIOSQP_COOP_EPI=0): same nodes, same ADMM iterations, same
+    bounds, same incumbent."""
+    from miosqp_amd import bnb
+    pr = sp.make(name)
+    st = dict(problems.BNB_SETTINGS, max_iter_bb=40, device_tree=False)
+    qs = dict(problems.QP_SETTINGS)
+
+    def run(device_search, env=None):
+        if env:
+            monkeypatch.setenv(*env)
+        mdl = bnb.MIOSQP()
+        mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                  dict(st, device_search=device_search), dict(qs))
+        assert mdl.work.solver.factor_stats()["coop"]
+        r = mdl.solve()
+        out = (r.status, mdl.work.iter_num, mdl.work.osqp_iter, r.upper_glob, mdl.work.lower_glob, None if r.x is None else r.x.copy())
+        assert (getattr(mdl.work, "_hosted", None) is not None) == device_search
+        if env:
+            monkeypatch.delenv(env[0])
+        return out
+
+    py, cc, ce = run(False), run(True), run(True, ("MIOSQP_COOP_EPI", "0"))
+    for got in (cc, ce):
+        assert got[:3] == py[:3]
+        for a, b in zip(got[3:5], py[3:5]):
+            assert (np.isinf(a) and np.isinf(b) and a == b) or abs(a - b) <= 1e-9 * max(1.0, abs(b))
+        assert (got[5] is None) == (py[5] is None)
+        if py[5] is not None and np.isfinite(py[3]):  # (without an incumbent x is whatever the workspace was created with)
+            np.testing.assert_array_equal(got[5][pr["i_idx"]], py[5][pr["i_idx"]])
+            assert rel(got[5], py[5]) <= SOL_TOL
+    # the two hosted searches took the same decisions from the same bits
+    assert cc[:3] == ce[:3] and cc[3] == ce[3]
+
+
 def _engine(pr, **kw):
     from miosqp_amd import qp
     A, l, u = problems.extended(pr)
