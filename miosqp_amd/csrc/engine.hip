@@ -1499,6 +1499,7 @@ static void kernel_bytes(const miosqp_qp_engine *e, double b[6]) {
   // what the kernels of the form in use REQUEST per iteration: the dense tail (and, in the product form, the
   // dense G block) carries no index array, so those entries move 8 bytes, not the 12 of the formula above
   b[5] = (e->fold ? 2 * ((double)n * M + nt) * 8 : 2 * (np * 12 + nt * 8)) + rest;
+  if (e->pers && e->pp.sinv && e->pp.res_w) b[5] -= n * (n - e->pp.res_c0) * 8;  // columns of S^-1 that stay in LDS
 }
 
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
@@ -1622,6 +1623,7 @@ int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which) {
     std::lock_guard<std::mutex> lk(t->mu);
     return t->users;
   }
+  if (which == 5) return (e->pers_capable && e->pp.sinv && e->pp.res_w) ? e->n - e->pp.res_c0 : 0;
   return which == 0 ? e->compactions : which == 1 ? e->kbp_fallbacks : -1;
 }
 

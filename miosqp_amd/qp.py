@@ -442,6 +442,10 @@ class OSQP(object):
     def chip_turn_users(self):
         return int(self._lib.miosqp_qp_debug_counter(self._h, 4))
 
+    def tail_inverse_resident_columns(self):
+        """Columns of every row of S^-1 the persistent streaming solver keeps in LDS for a whole launch (0: none)."""
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 5))
+
     def call_off_word(self):
         """The control block's call-off / time-out word once the engine's stream is idle (0: nothing happened)."""
         return int(self._lib.miosqp_qp_debug_counter(self._h, 3))

@@ -1150,6 +1150,46 @@ def test_cooperative_solver_reports_a_missing_workgroup_and_recovers(oracle_mod,
     assert rel(rg.x, ro.x) <= SOL_TOL
 
 
+def test_persistent_solver_with_resident_columns_of_the_tail_inverse(oracle_mod, monkeypatch):
+    """Factor form with the tail as S^-1 (pers = 2): the last columns of a workgroup's rows of S^-1 stay in its LDS for
+    the whole launch and only the rest is streamed every iteration (config 5: 392 of 5000 columns).  At sizes a test can
+    afford the space is normally taken by the termination test's y and dy; MIOSQP_PERS_TEST_SPARSE=1 frees it.  Odd and
+    even n, rows of S^-1 shorter and longer than the resident block can cut, against the oracle and against the same
+    engine without the resident block (MIOSQP_PERS_RESIDENT=0): status, iterations, x, y."""
+    from miosqp_amd import qp
+    monkeypatch.setenv("MIOSQP_PERS_TEST_SPARSE", "1")
+    rng = np.random.RandomState(99)
+    seen = 0
+    for trial, (n, m, p) in enumerate([(257, 300, 40), (300, 450, 100), (301, 520, 33), (384, 200, 50), (511, 700, 120),
+                                       (640, 900, 200), (777, 400, 10), (130, 300, 20), (900, 300, 60)]):
+        pr = problems.random_miqp(n, m, p, density=0.3, seed=7000 + trial)
+        A, l, u = problems.extended(pr)
+        M = A.shape[0]
+        o = oracle_mod.OSQP()
+        o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+        x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(M)
+        o.warm_start(x=x0, y=y0)
+        ro = o.solve()
+        res = []
+        for keep in ("1", "0"):
+            monkeypatch.setenv("MIOSQP_PERS_RESIDENT", keep)
+            g = qp.OSQP()
+            g.setup(pr["P"], pr["q"], A, l, u, fold=0, resident=0, coop=0, pers=2, **problems.QP_SETTINGS)
+            fs = g.factor_stats()
+            assert fs["pers"] and fs["tail_inverse"], (n, m, p)
+            cols = g.tail_inverse_resident_columns()
+            assert (cols == 0) if keep == "0" else (cols == 0 or 128 <= cols <= n // 2 + 1), (n, cols)
+            seen += keep == "1" and cols > 0
+            g.warm_start(x=x0, y=y0)
+            rg = g.solve()
+            assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), (n, m, p, keep)
+            assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL, (n, m, p, keep)
+            res.append(rg)
+            g.close()
+        assert rel(res[0].x, res[1].x) <= 1e-10
+    assert seen >= 5  # (the small ones have no room for a block of 128 columns within half a row)
+
+
 def test_persistent_solver_reports_a_missing_workgroup_and_recovers(monkeypatch):
     """The fault of the test above on the persistent streaming solver (both kernels: the lean product-form one and the
     general one in factor form): the launch is called off before any iterate is touched, the same call is redone in the
