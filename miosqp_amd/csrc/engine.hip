@@ -328,6 +328,7 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (e->search) {
     NodeSearch *S = static_cast<NodeSearch *>(e->search);
     if (S->dg) hipHostFree(S->dg);
+    if (S->own_block) hipFree(S->own_block);
     for (hipEvent_t ev : S->ev)
       if (ev) hipEventDestroy(ev);
     delete S;
