@@ -400,7 +400,7 @@ def cpu_baseline(prob, budget_s):
                        % (srch.nodes, srch.iters, dt, info["nproc"] or 0, what))
 
 
-def rho_auto_leg(prob, cfg, seed, local_rank, nodes):
+def rho_auto_leg(prob, cfg, seed, local_rank, nodes, batched_chunks=0):
     """The headline workload with rho chosen ONCE per MIQP at setup (qp setting rho="auto": OSQP's own update rule applied
     to the root's iterates, then frozen -- one factor for every node as before) next to the frozen default rho = 0.1 of
     `value`.  The reference passes only eps_* to osqp.setup (/root/reference/miosqp/workspace.py:67-68), i.e. OSQP's
@@ -456,6 +456,40 @@ def rho_auto_leg(prob, cfg, seed, local_rank, nodes):
                rho=eng.rho(), rho_default=0.1, setup_s=round(t_setup, 3), nodes=dn, value=round(di / dt, 1),
                unit="ADMM iter/s", nodes_per_s=round(dn / dt, 2), iters_per_node=round(di / max(1, dn), 1),
                ms_per_node=round(1e3 * dt / max(1, dn), 4), one_tree=tree)
+    if batched_chunks > 0:
+        # configs[2] with the same rho: the stream on the device-resident leaf pool (the `batched` leg's form), 256 columns
+        from miosqp_amd import stream as stream_mod
+        model.work.leaves = []
+        model.update_vectors(q=rng.randn(cfg["n"]), l=-2 + rng.rand(m_orig), u=2 + rng.rand(m_orig))
+        ss = stream_mod.NativeStreamSearch(model, columns=256)
+        closed = []
+
+        def chunks(count):
+            for _ in range(count):
+                if ss.step() == 0:
+                    closed.append((time.perf_counter(), ss.nodes))
+                    model.update_vectors(q=rng.randn(cfg["n"]), l=-2 + rng.rand(m_orig), u=2 + rng.rand(m_orig))
+                    ss.begin_instance()
+
+        chunks(max(40, batched_chunks // 5))
+        torch.cuda.synchronize()
+        eng.batch_stats(reset=True)
+        del closed[:]
+        n2, i2, t2 = ss.nodes, ss.iters, time.perf_counter()
+        chunks(batched_chunks)
+        eng.pool_collect(0)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t2
+        sms, sit, snode = eng.batch_stats()
+        bt = dict(width=256, chunks=batched_chunks, nodes=ss.nodes - n2, node_iters_per_s=round((ss.iters - i2) / dts, 1),
+                  nodes_per_s=round((ss.nodes - n2) / dts, 2), iters_per_node=round((ss.iters - i2) / max(1, ss.nodes - n2), 1),
+                  device_us_per_lockstep_iter=round(1e3 * sms / max(1, sit), 2),
+                  column_occupancy=round(snode / float(max(1, 256 * sit)), 3), closed_in_timed_region=len(closed))
+        if len(closed) >= 2:
+            gaps = [closed[k][0] - closed[k - 1][0] for k in range(1, len(closed))]
+            bt.update(mean_ms_to_close=round(1e3 * float(np.mean(gaps)), 3),
+                      mean_nodes_per_tree=round(float(np.mean([closed[k][1] - closed[k - 1][1] for k in range(1, len(closed))])), 1))
+        out["batched"] = bt
     eng.close()
     return out
 
@@ -975,7 +1009,8 @@ def main():
             if "config1" in legs:
                 out["config1"] = small_leg(args.seed, local_rank)
             if "rho_auto" in legs and hosted:
-                out["rho_auto"] = rho_auto_leg(prob, cfg, args.seed, local_rank, max(150, args.steps))
+                out["rho_auto"] = rho_auto_leg(prob, cfg, args.seed, local_rank, max(150, args.steps),
+                                               batched_chunks=args.stream_chunks if "batched" in legs else 0)
         if world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
         print(json.dumps(out))
