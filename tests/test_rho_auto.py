@@ -103,6 +103,40 @@ def test_engine_chooses_the_oracles_rho_and_follows_it(oracle_mod, n, m, p, seed
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["milp", "low_rank_P", "equality_rows", "one_sided_rows", "A_5pct", "badly_scaled",
+                                  "power_converter_K10"])
+def test_rho_chosen_at_setup_on_structured_instances(oracle_mod, name):
+    """The rule on matrices that are not random-dense (P = 0, rank-deficient P, equality and one-sided rows, sparse A, badly
+    scaled rows, the power converter's blocks; tests/structured_problems.py): the engine and the oracle choose the same
+    two digits and the root and a child end in the same status after the same number of iterations."""
+    import structured_problems as sp
+    from miosqp_amd import qp
+    pr = sp.make(name)
+    A, l, u = problems.extended(pr)
+    n, M, m = A.shape[1], A.shape[0], pr["A"].shape[0]
+    st = dict(problems.QP_SETTINGS, rho="auto")
+    g, o = qp.OSQP(), oracle_mod.OSQP()
+    g.setup(pr["P"], pr["q"], A, l, u, **st)
+    o.setup(pr["P"], pr["q"], A, l, u, **st)
+    g.set_integer_rows(pr["i_idx"], m)
+    assert g.rho() == o.rho() and g.rho() > 0
+    x, y = np.zeros(n), np.zeros(M)
+    lo, hi = l.copy(), u.copy()
+    for level in range(2):
+        r = g.solve_node(lo, hi, x, y)
+        o.update(l=lo, u=hi)
+        o.warm_start(x=x, y=y)
+        ro = o.solve()
+        assert (r.status_val, r.iter) == (ro.info.status_val, ro.info.iter), level
+        if ro.info.status_val != 1:
+            break
+        assert np.max(np.abs(r.y - ro.y)) <= 1e-7 * max(1.0, np.max(np.abs(ro.y)))
+        hi = hi.copy()
+        hi[m] = lo[m]
+        x, y = r.x, r.y
+
+
+@pytest.mark.gpu
 def test_config2_tree_with_rho_chosen_at_setup():
     """the headline workload both ways: the same optimum, a third of the iterations per node"""
     out = {}
