@@ -31,6 +31,7 @@
 #include <queue>
 #include <deque>
 #include <tuple>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -227,6 +228,7 @@ struct CoopNode {
 #include "kernels_bpers.inc"  // batched mode: a chunk's lock-step iterations as one persistent launch, the factor in registers and LDS (kbp)
 #include "kernels_tree.inc"  // a whole branch-and-bound tree in one launch (LDS-resident problems)
 #include "kernels_pool.inc"  // device-resident leaf pool, streaming batch (refill / harvest between chunks)
+#include "kernels_bstream.inc"  // the streaming batch as ONE persistent launch: iterations, test, harvest and refill per column group (kbs)
 #include "host.inc"  // host side: engine object, allocation, launches, graph capture, solve loops
 #include "host_pool.inc"  // host side of the leaf pool (C ABI miosqp_qp_pool_*)
 #include "host_search.inc"  // node-at-a-time branch and bound driven from the host in C++ (C ABI miosqp_qp_search_*)
@@ -239,7 +241,7 @@ namespace {
 // the dynamic-LDS ceiling of a kernel is a property of (process, device, kernel): raised to the chip's 160 KB once instead of
 // at every set-up (the call costs ~40 us, a fifth of a small problem's set-up)
 hipError_t lds_limit_once(const void *fn, int which) {
-  static bool done[9][64] = {};
+  static bool done[12][64] = {};
   int dev = 0;
   hipError_t rc = hipGetDevice(&dev);
   if (rc != hipSuccess) return rc;
@@ -292,7 +294,13 @@ int miosqp_qp_constant(const char *name) {
 int miosqp_qp_cleanup(miosqp_qp_engine *e) {
   if (!e) return 0;
   if (e->device >= 0) (void)hipSetDevice(e->device);
+  kbs_stop(e);  // (a persistent launch of the stream still queued leaves at its next chunk boundary)
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->side) {
+    hipStreamSynchronize(e->side);
+    hipStreamDestroy(e->side);
+    e->side = nullptr;
+  }
   chip_quit(e);
   if (e->x_full) hipGraphExecDestroy(e->x_full);
   if (e->x_tail) hipGraphExecDestroy(e->x_tail);
@@ -736,7 +744,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           if (!rc) rc = dalloc(e, &d.coop_reg, 128);
           if (!rc) rc = dalloc(e, &d.coop_chz, d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_dec, 64);
-          if (!rc) rc = dalloc(e, &e->coop_epi, 2 * (size_t)(2 * 1024 + 256) + 64);
+          if (!rc) rc = dalloc(e, &e->coop_epi, 2 * (size_t)COOP_EPI_ENTRIES + 64);
           {
             // the test on workgroups of its own when the exchange grid leaves enough CUs free
             d.coop_nt = coop_pick_testers(prop.multiProcessorCount - T);
@@ -1547,6 +1555,21 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
 // debug: per-block (start, end) wall-clock stamps (100 MHz) of ONE launch of a product-form kernel
 int miosqp_qp_debug_timeline(miosqp_qp_engine *e, int32_t which, uint64_t *out, int32_t max_blocks,
                              int32_t *nblocks) {
+  if (which == 6) {
+    // the persistent stream's own phase clocks (MIOSQP_KBS_PROF=1), summed over the launches since the last call; per
+    // workgroup 8 words: shader clocks of thread 0 in {iterations, test, harvest + refill, -}, chunks, -, -, -; then per
+    // workgroup 8 more: the phases inside the iterations {forward sweep, reduce + store, barrier, x sweep, x epilogue,
+    // constraint tiles, barrier}, -; then per workgroup 16: the phases inside the boundaries {test jobs, row pieces + fold,
+    // barrier, members' fold + decision, harvest rows + claim, barrier, table + harvest jobs + fold, prepare, barrier, commit,
+    // z jobs + stores, barrier, counters}
+    if (!e || !out || !e->kbs_prof || max_blocks < 16 * KBP_WGS) return MIOSQP_EARG;
+    ENTER(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->kbs_prof, sizeof(unsigned long long) * 32 * KBP_WGS, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->kbs_prof, 0, sizeof(unsigned long long) * 32 * KBP_WGS));
+    if (nblocks) *nblocks = 16 * KBP_WGS;
+    return 0;
+  }
   if (!e || !out || which < 0 || which > 5 || (which < 4 && !e->fold) || (which == 2 && !e->coop) || (which == 3 && e->Bcap == 0) ||
       (which == 4 && !e->pers) || (which == 5 && !e->kbp))
     return MIOSQP_EARG;
