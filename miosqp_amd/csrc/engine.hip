@@ -403,10 +403,26 @@ static double rho_estimate_host(const miosqp::Scaled &sc, double rho, const doub
 
 int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t *Pp, const int32_t *Pi,
                     const double *Px, const int32_t *Ap, const int32_t *Ai, const double *Ax,
-                    const double *q, const double *l, const double *u, const miosqp_qp_settings *s) {
-  if (!out || n <= 0 || M < 0 || !Pp || !Ap || !q || !s || (M > 0 && (!l || !u))) {
+                    const double *q, const double *l, const double *u, const miosqp_qp_settings *s_in) {
+  if (!out || n <= 0 || M < 0 || !Pp || !Ap || !q || !s_in || (M > 0 && (!l || !u))) {
     g_err = "setup: bad argument";
     return MIOSQP_EARG;
+  }
+  miosqp_qp_settings s_own = *s_in;
+  miosqp_qp_settings *s = &s_own;
+  // rho chosen at set-up (rho_auto), r05: ONE set-up.  The probing iterations run on THIS engine, in the plain four-kernel
+  // factor form, the moment its factor at the starting rho is on the device (before the product form, the explicit
+  // inverse, graphs and calibrations exist); then only what depends on rho is built again -- the factor, on the host --
+  // and copied over the first one.  Measured at config 2: 153 ms (two set-ups) -> see DESIGN.md; the equilibration, the
+  // allocations, the runtime objects, the product form, the inverse, captures and calibrations happen once.
+  // Kept on the two-set-up path: problems factorised on the device (n >= 1024: the factor never visits the host) and
+  // the small ones whose probe engine is the one-workgroup solver (fifty iterations there cost less than 200 launches).
+  bool probe_inline = false;
+  if (s->rho_auto && M > 0) {
+    int on_dev_pre = s->setup_on_device;
+    if (on_dev_pre < 0) on_dev_pre = n >= 1024 ? 1 : 0;
+    probe_inline = !on_dev_pre && n + M > 400 && !getenv("MIOSQP_RHO_TWO_SETUPS");
+    if (probe_inline) s->rho_auto = 0;
   }
   if (s->rho_auto && M > 0) {
     // a throw-away engine in the plain multi-kernel form for the probing iterations, then the real one at the chosen
@@ -629,6 +645,43 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->tpr_tail = pick_tpr(0.5 * n);
   e->tpr_pb = pick_tpr((double)f.Pbar.nnz / n);
   e->tpr_pr = pick_tpr((double)f.Praw.nnz / n);
+  if (probe_inline) {
+    // rho_once (oracle/qp_oracle.c): RHO_ONCE_ITERS iterations from zero on the set-up's bounds, the rule, a new factor
+    std::vector<double> xs(n), zs(M), ys(M);
+    {
+      const int big = n > M ? n : M;
+      hipLaunchKernelGGL(k_zero_iterates, dim3((big + 255) / 256), dim3(256), 0, e->stream, d);
+    }
+    int rc = miosqp_qp_debug_iterate(e, RHO_ONCE_ITERS, xs.data(), zs.data(), ys.data());
+    if (rc) { miosqp_qp_cleanup(e); return rc; }
+    const double rho_new = rho_estimate_host(e->sc, s->rho, xs.data(), zs.data(), ys.data());
+    tick("rho chosen at set-up: probing iterations + the rule");
+    if (rho_new > 0 && rho_new != s->rho) {
+      std::string err2;
+      if (!miosqp::build_factor(e->sc, Pp, Pi, Px, rho_new, s->sigma, e->fa, err2, nullptr, nullptr, true)) {
+        g_err = err2;
+        miosqp_qp_cleanup(e);
+        return MIOSQP_EFACTOR;
+      }
+      const miosqp::Factor &f2 = e->fa;  // same patterns, same sizes: copied over the first factor
+      HIPCHK(hipMemcpy(const_cast<double *>(d.pv_L), f2.panel_by_var.val.data(), sizeof(double) * f2.panel_by_var.val.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(const_cast<double *>(d.pc_L), f2.panel_by_con.val.data(), sizeof(double) * f2.panel_by_con.val.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(const_cast<double *>(d.Linv), f2.Linv.data(), sizeof(double) * f2.Linv.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(const_cast<double *>(d.LinvT), f2.LinvT.data(), sizeof(double) * f2.LinvT.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(const_cast<double *>(d.d2inv), f2.d2inv.data(), sizeof(double) * f2.d2inv.size(), hipMemcpyHostToDevice));
+      s->rho = rho_new;
+      e->st.rho = rho_new;
+      d.rho = rho_new;
+      d.rho_inv = 1.0 / rho_new;
+      tick("rho chosen at set-up: the factor again");
+    }
+    e->st.rho_auto = 1;
+    {
+      const int big = n > M ? n : M;
+      hipLaunchKernelGGL(k_zero_iterates, dim3((big + 255) / 256), dim3(256), 0, e->stream, d);
+    }
+    hipLaunchKernelGGL(k_reset_ctrl, dim3(1), dim3(1), 0, e->stream, d);
+  }
   {
     // product-form factor: worth it when the panel is dense (bytes no worse, half the launches); decided above
     const int want = want_fold;

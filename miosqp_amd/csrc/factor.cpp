@@ -323,7 +323,7 @@ bool scale_problem(int n, int M, const int32_t *Pp, const int32_t *Pi, const dou
 
 bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
                   const double *Px_raw, double rho, double sigma, Factor &f, std::string &err,
-                  DenseLdlInv accel, void *accel_ctx) {
+                  DenseLdlInv accel, void *accel_ctx, bool reuse_rows) {
   const int n = s.n, M = s.M;
   StageTimer tm;
   f.n = n;
@@ -333,8 +333,13 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
   f.ld = (n + 15) & ~15;  // multiples of 16: the batched matrix-core tiles read whole 16-deep chunks of a row
   const int ld = f.ld;
 
+  if (reuse_rows) {
+    // (a padding entry is 0.0 in a fresh build, not -rho * 0.0 = -0.0)
+    for (size_t k = 0; k < f.At_val.size(); k++) f.panel_by_var.val[k] = f.At_val[k] == 0.0 ? 0.0 : -rho * f.At_val[k];
+    for (size_t k = 0; k < f.A_val.size(); k++) f.panel_by_con.val[k] = f.A_val[k] == 0.0 ? 0.0 : -rho * f.A_val[k];
+  }
   // ---- panel: rows of Abar^T (per variable) and rows of Abar (per constraint) ----------
-  {
+  if (!reuse_rows) {
     std::vector<std::vector<Triplet>> byvar(n), bycon(M);
     for (int i = 0; i < n; i++) byvar[i].reserve(s.Ap[i + 1] - s.Ap[i]);
     for (int i = 0; i < n; i++)
@@ -350,7 +355,7 @@ bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
   }
   tm.lap("panel rows");
   // ---- symmetric matrices by row (counting transpose of the upper triangle; columns ascend) ----
-  {
+  if (!reuse_rows) {
     // Row r of the full symmetric matrix = [column r of the upper triangle: entries (i, r), i <= r, as columns i]
     // followed by [row r of the strict upper triangle: entries (r, j), j > r] -- both ascending, so the row comes out
     // sorted.  The first part is copied per row; the second is a transpose of the strict upper triangle done in

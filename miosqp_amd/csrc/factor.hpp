@@ -133,8 +133,11 @@ struct DenseAccelCtx {
 };
 
 // Builds the factor; returns false with `err` set when D22 loses positivity.
+// reuse_rows: `f` holds the factor of the SAME matrices at another rho (rho chosen at set-up): the packed rows -- patterns,
+// the plain values of Abar / Abar^T, the symmetric matrices -- are kept, the panel's values are formed from the plain
+// ones with the new rho (-rho a: the same product a fresh build forms) and only the dense part is built again.
 bool build_factor(const Scaled &s, const int32_t *Pp_raw, const int32_t *Pi_raw,
                   const double *Px_raw, double rho, double sigma, Factor &f, std::string &err,
-                  DenseLdlInv accel = nullptr, void *accel_ctx = nullptr);
+                  DenseLdlInv accel = nullptr, void *accel_ctx = nullptr, bool reuse_rows = false);
 
 }  // namespace miosqp

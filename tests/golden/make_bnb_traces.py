@@ -2,7 +2,13 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_bnb_traces.py
+    python tests/golden/make_bnb_traces.py              # the frozen default rho = 0.1:   bnb_<case>.npz
+    python tests/golden/make_bnb_traces.py --rho-auto   # rho chosen once at set-up:      bnb_rhoauto_<case>.npz
+
+(second set, round 5: `rho="auto"` -- OSQP's own update rule applied once at set-up, then frozen, DESIGN.md sec. 1 -- is
+what comes closest to the reference's actual settings, which leave rho to OSQP's adaptive default
+(/root/reference/miosqp/workspace.py:67-68); the same cases searched by the reference's tree search with that setting in
+the shim, so that the mode is pinned count for count like the default.)
 
 The reference's B&B layer (/root/reference/miosqp/*.py) imports a module called `osqp`
 (node.py:2, workspace.py:6) that is not installed here.  A shim module with the same surface
@@ -83,7 +89,11 @@ def run_reference(prob, settings, qp_settings, x0=None, updates=()):
     return out
 
 
+PREFIX = ""  # "rhoauto_" for the second fixture set
+
+
 def save_case(name, prob, settings, qp_settings, solves, updates=(), x0=None):
+    name = PREFIX + name
     P = spa.csc_matrix(prob["P"]); A = spa.csc_matrix(prob["A"])
     P.sort_indices(); A.sort_indices()
     d = dict(P_indptr=P.indptr, P_indices=P.indices, P_data=P.data, P_shape=P.shape,
@@ -113,7 +123,12 @@ def save_case(name, prob, settings, qp_settings, solves, updates=(), x0=None):
 
 
 def main():
+    global PREFIX
+    auto = "--rho-auto" in sys.argv
+    PREFIX = "rhoauto_" if auto else ""
     qp = dict(problems.QP_SETTINGS)
+    if auto:
+        qp["rho"] = "auto"
     base = dict(problems.BNB_SETTINGS)
     cases = [
         ("n10m5p2_s0", dict(n=10, m=5, p=2), 0, {}, {}),
@@ -129,7 +144,9 @@ def main():
     for name, dims, seed, so, qo in cases:
         prob = problems.random_miqp(density=0.7, seed=seed, **dims)
         st = dict(base); st.update(so)
-        qs = dict(qp); qs.update(qo)
+        qs = dict(qp)
+        if not auto:
+            qs.update(qo)
         save_case(name, prob, st, qs, run_reference(prob, st, qs))
 
     # infeasible relaxation at the root (contradictory rows)

@@ -1,6 +1,6 @@
 """Golden fixture for BASELINE config 4: power_converter MPC, horizon N=3 (n=18).
 
-Run in the build container only:  python tests/golden/make_power_converter.py
+Run in the build container only:  python tests/golden/make_power_converter.py [--rho-auto]
 
 Imports the REFERENCE's example package from /root/reference (with stand-in modules only for the
 absent third-party imports it never uses on this path: `osqp` -> the CPU oracle with the osqp
@@ -27,8 +27,19 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
 
+AUTO = "--rho-auto" in sys.argv  # second fixture: rho chosen once at set-up, *_rhoauto.npz
+
+
+class _AutoRho(oracle.OSQP):
+    """the oracle with rho = "auto" whatever the caller passes: the reference's example hands only eps_* to osqp.setup"""
+
+    def setup(self, *a, **kw):
+        kw["rho"] = "auto"
+        return oracle.OSQP.setup(self, *a, **kw)
+
+
 shim = types.ModuleType("osqp")
-shim.OSQP = oracle.OSQP
+shim.OSQP = _AutoRho if AUTO else oracle.OSQP
 shim.constant = oracle.constant
 sys.modules["osqp"] = shim
 sys.modules["mathprogbasepy"] = types.ModuleType("mathprogbasepy")
@@ -89,7 +100,9 @@ def main():
         u_mpc = res.x
         x = np.asarray(model.dyn_system.A.dot(x) + model.dyn_system.B.dot(u_mpc[:6])).ravel()
         u_prev = np.append(u_mpc[nu:], u_mpc[-nu:])
-    out = os.path.join(HERE, "power_converter_N3.npz")
+    if AUTO:
+        qp_settings = dict(qp_settings, rho="auto")
+    out = os.path.join(HERE, "power_converter_N3_rhoauto.npz" if AUTO else "power_converter_N3.npz")
     np.savez_compressed(
         out, P_indptr=P.indptr, P_indices=P.indices, P_data=P.data, P_shape=P.shape,
         A_indptr=A.indptr, A_indices=A.indices, A_data=A.data, A_shape=A.shape, l=l0,

@@ -1,7 +1,7 @@
 """Golden fixture for the power-converter benchmark harness: one settling period + one
 measured period of the reference's closed-loop simulation at horizon N=3.
 
-Run in the build container only:  python tests/golden/make_power_converter_long.py
+Run in the build container only:  python tests/golden/make_power_converter_long.py [--rho-auto]
 
 Imports the REFERENCE's example package from /root/reference (stand-in modules only for third-party imports
 absent here that this path never exercises: `osqp` -> the CPU oracle with the osqp surface, `mathprogbasepy`,
@@ -27,8 +27,19 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
 
+AUTO = "--rho-auto" in sys.argv  # second fixture: rho chosen once at set-up, *_rhoauto.npz
+
+
+class _AutoRho(oracle.OSQP):
+    """the oracle with rho = "auto" whatever the caller passes: the reference's example hands only eps_* to osqp.setup"""
+
+    def setup(self, *a, **kw):
+        kw["rho"] = "auto"
+        return oracle.OSQP.setup(self, *a, **kw)
+
+
 shim = types.ModuleType("osqp")
-shim.OSQP = oracle.OSQP
+shim.OSQP = _AutoRho if AUTO else oracle.OSQP
 shim.constant = oracle.constant
 sys.modules["osqp"] = shim
 sys.modules["mathprogbasepy"] = types.ModuleType("mathprogbasepy")
@@ -92,7 +103,9 @@ def main():
         u_prev = np.append(u_full[nu:], u_full[-nu:])
     Y_phase, Y_star_phase, T_e, T_e_des = model.compute_signals(X)
     stats = model.get_statistics(SimulationResults(X, U, Y_phase, Y_star_phase, T_e, T_e_des, solve_times))
-    out = os.path.join(HERE, "power_converter_N3_long.npz")
+    if AUTO:
+        qp_settings = dict(qp_settings, rho="auto")
+    out = os.path.join(HERE, "power_converter_N3_long_rhoauto.npz" if AUTO else "power_converter_N3_long.npz")
     np.savez_compressed(
         out, P_indptr=P.indptr, P_indices=P.indices, P_data=P.data, P_shape=P.shape,
         A_indptr=A.indptr, A_indices=A.indices, A_data=A.data, A_shape=A.shape, l=l0,

@@ -86,9 +86,9 @@ def load_maxiter():
     return out
 
 
-def load_power_converter():
+def load_power_converter(name="power_converter_N3.npz"):
     from miosqp_amd import problems
-    return problems.load_power_converter(os.path.join(GOLDEN, "power_converter_N3.npz"))
+    return problems.load_power_converter(os.path.join(GOLDEN, name))
 
 
 def run_power_converter(pc, backend, steps=None):

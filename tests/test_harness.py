@@ -12,10 +12,12 @@ from miosqp_amd import harness, problems
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LONG = os.path.join(ROOT, "tests", "golden", "power_converter_N3_long.npz")
+LONG_AUTO = os.path.join(ROOT, "tests", "golden", "power_converter_N3_long_rhoauto.npz")  # rho chosen once at set-up
 
 
-def test_switching_frequency_and_thd_match_the_reference():
-    pc = problems.load_power_converter(LONG)
+@pytest.mark.parametrize("path", [LONG, LONG_AUTO])
+def test_switching_frequency_and_thd_match_the_reference(path):
+    pc = problems.load_power_converter(path)
     fsw, thd = harness.closed_loop_statistics(pc)
     assert abs(fsw - pc["fsw"]) <= 1e-12 * max(1.0, abs(pc["fsw"]))
     assert abs(thd - pc["thd"]) <= 1e-10 * max(1.0, abs(pc["thd"]))
@@ -23,6 +25,32 @@ def test_switching_frequency_and_thd_match_the_reference():
     t = harness.on_transitions(np.array([1, 0, -1]), np.array([0, 1, 0]))
     assert list(np.nonzero(t)[0]) == [0, 6, 11]
     assert not harness.on_transitions(np.array([1, -1, 0]), np.array([-1, 1, 0])).any()  # two-level jumps do not count
+
+
+@pytest.mark.parametrize("path", [LONG_AUTO])
+def test_recorded_loop_with_rho_chosen_at_setup(oracle_mod, path):
+    """the closed loop the reference recorded with `rho="auto"` in the shim (1600 MIQPs on ONE factor whose rho was chosen
+    from the first step's vectors): the first 400 steps replayed on the oracle, count for count"""
+    pc = problems.load_power_converter(path)
+    assert pc["qp_settings"]["rho"] == "auto"
+    recs, _ = problems.run_power_converter(pc, oracle_mod, 400)
+    for k, r in enumerate(recs):
+        assert r["status"] == "Solved"
+        assert (r["nodes"], r["osqp_iter"]) == (int(pc["nodes"][k]), int(pc["osqp_iter"][k])), k
+        np.testing.assert_array_equal(r["x"][:6], pc["U"][:, k])
+
+
+@pytest.mark.gpu
+def test_recorded_loop_with_rho_chosen_at_setup_on_gpu():
+    """... and all 1600 steps on the HIP engine: the same rho, the same node and iteration counts, the recorded inputs"""
+    from miosqp_amd import qp
+    pc = problems.load_power_converter(LONG_AUTO)
+    recs, model = problems.run_power_converter(pc, qp)
+    assert len(recs) == 1600
+    for k, r in enumerate(recs):
+        assert r["status"] == "Solved"
+        assert (r["nodes"], r["osqp_iter"]) == (int(pc["nodes"][k]), int(pc["osqp_iter"][k])), k
+        assert np.max(np.abs(r["x"][:6] - pc["U"][:, k])) <= 1e-6
 
 
 def test_power_converter_harness_closes_the_recorded_loop(oracle_mod, tmp_path):

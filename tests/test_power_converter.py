@@ -1,14 +1,21 @@
 """BASELINE config 4: power_converter MPC horizon N=3 (n=18, 45 rows, l = -inf rows, P with
 eigenvalues down to 1e-19): 40 consecutive MIQPs sharing one factorisation through
-update_vectors + set_x0, recorded from the reference (tests/golden/make_power_converter.py)."""
+update_vectors + set_x0, recorded from the reference (tests/golden/make_power_converter.py) -- with the frozen default
+rho = 0.1 and, second fixture, with rho chosen once at set-up (`rho="auto"`: the set-up's q decides, the 39 later q's of the
+sequence run on that factor)."""
 import numpy as np
 import pytest
 
 from golden_cases import load_power_converter, run_power_converter
 
 
-def test_mpc_sequence_matches_reference_cpu(oracle_mod):
-    pc = load_power_converter()
+FIXTURES = ["power_converter_N3.npz", "power_converter_N3_rhoauto.npz"]
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_mpc_sequence_matches_reference_cpu(oracle_mod, fixture):
+    pc = load_power_converter(fixture)
+    assert (pc["qp_settings"].get("rho") == "auto") == ("rhoauto" in fixture)
     got = run_power_converter(pc, oracle_mod)
     for k, g in enumerate(got):
         assert g["status"] == pc["status"][k] == "Solved"
@@ -18,12 +25,50 @@ def test_mpc_sequence_matches_reference_cpu(oracle_mod):
 
 
 @pytest.mark.gpu
-def test_mpc_sequence_matches_reference_gpu():
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_mpc_sequence_matches_reference_gpu(fixture):
     from miosqp_amd import qp
-    pc = load_power_converter()
+    pc = load_power_converter(fixture)
     got = run_power_converter(pc, qp)
     for k, g in enumerate(got):
         assert g["status"] == pc["status"][k]
         assert g["nodes"] == pc["nodes"][k] and g["osqp_iter"] == pc["osqp_iter"][k], k
         assert abs(g["upper"] - pc["upper"][k]) <= 1e-8 * max(1.0, abs(pc["upper"][k]))
         np.testing.assert_allclose(g["x"], pc["x"][k], rtol=0, atol=1e-8)
+
+
+def test_rho_chosen_at_setup_serves_the_whole_mpc_sequence(oracle_mod):
+    """`rho="auto"` looks at the set-up's q only; MIOSQP.update_vectors (/root/reference/miosqp/solver.py:174-205) then
+    changes q at every MPC step without a new choice.  That is enough, and this test is the argument: asked again for every
+    step's own q and u the rule answers anything between 0.052 and 1.1 (set-up: 0.18) -- but the 40-step sequence costs
+    23 500 ADMM iterations on the set-up's rho against 23 175 with a fresh choice AND a fresh factorisation per step
+    (1.4 %; rho fixed at 0.05 / 0.1 / 0.3 / 1.0: 32 500 / 24 625 / 22 725 / 24 775): the iteration count is flat around the
+    set-up's value, a re-estimate would buy nothing and cost a factorisation per MPC step."""
+    from miosqp_amd import bnb, problems
+    pc = load_power_converter("power_converter_N3_rhoauto.npz")
+    l = pc["l"].copy()
+    setup_rho, per_step_rho, it_setup, it_fresh = None, [], 0, 0
+    model = None
+    for k in range(len(pc["q"])):
+        q, u = pc["q"][k].copy(), pc["u"][k].copy()
+        fresh = bnb.MIOSQP(backend=oracle_mod)   # a new choice of rho for this step's vectors
+        fresh.setup(pc["P"], q, pc["A"], l, u, pc["i_idx"], pc["i_l"], pc["i_u"], pc["settings"], pc["qp_settings"])
+        fresh.set_x0(pc["x0"][k].copy())
+        rf = fresh.solve()
+        per_step_rho.append(fresh.work.solver.rho())
+        it_fresh += fresh.work.osqp_iter
+        if model is None:
+            model = bnb.MIOSQP(backend=oracle_mod)
+            model.setup(pc["P"], q, pc["A"], l, u, pc["i_idx"], pc["i_l"], pc["i_u"], pc["settings"], pc["qp_settings"])
+            setup_rho = model.work.solver.rho()
+        else:
+            model.update_vectors(q, l, u)
+        model.set_x0(pc["x0"][k].copy())
+        rs = model.solve()
+        it_setup += model.work.osqp_iter
+        assert rs.status == rf.status == "Solved"
+        assert abs(rs.upper_glob - rf.upper_glob) <= 1e-2 * max(1.0, abs(rf.upper_glob))
+    per_step_rho = np.array(per_step_rho)
+    assert per_step_rho[0] == setup_rho
+    assert per_step_rho.min() < 0.5 * setup_rho and per_step_rho.max() > 2.0 * setup_rho  # the rule does move with q ...
+    assert it_setup <= 1.05 * it_fresh, (it_setup, it_fresh)                              # ... and it does not matter
