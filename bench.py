@@ -680,6 +680,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loop_ms, loop_iters = eng.loop_stats()
+    node_us = eng.node_stats() if hasattr(eng, "node_stats") else None  # (min, median, max us per iteration over the nodes, count)
     nodes_here = head.nodes - n0
     tot = comm.sum([head.iters - i0, head.nodes - n0, dt])
     if hosted:
@@ -967,6 +968,11 @@ def main():
                                comm=type(comm).__name__ + ("/nccl" if (td is not None and not one_dev) else "")),
                    roofline=roof)
         out["config"]["instances_in_timed_region"] = instances
+        if node_us is not None and node_us[3] > 0:
+            # the timed region is a few dozen nodes on the driver's command: the spread over the nodes travels with the mean
+            out["usec_per_iter_over_nodes"] = dict(min=round(node_us[0], 4), median=round(node_us[1], 4), max=round(node_us[2], 4),
+                                                   nodes=node_us[3], mean=round(1e3 * loop_ms / max(1, loop_iters), 4),
+                                                   what="device time of a node's launch / its ADMM iterations (HIP events)")
         if pyloop is not None:
             out["python_loop"] = pyloop
         if batched is not None and batched["lockstep_iters"] > 0:
@@ -1011,6 +1017,19 @@ def main():
             if "rho_auto" in legs and hosted:
                 out["rho_auto"] = rho_auto_leg(prob, cfg, args.seed, local_rank, max(150, args.steps),
                                                batched_chunks=args.stream_chunks if "batched" in legs else 0)
+                # both settings of rho side by side at the top level: "ADMM iterations/s" rewards the setting that needs more
+                # iterations per node, nodes/s and the time to close a tree -- the other half of BASELINE's metric -- do not
+                ra = out["rho_auto"]
+                t01 = trees.get("one_tree_after_the_timed_region") or {}
+                out["by_rho"] = {
+                    "0.1 (frozen default: `value`)": dict(
+                        rho=0.1, admm_iter_per_s=out["value"], nodes_per_s=out["nodes_per_s"], iters_per_node=out["iters_per_node"],
+                        ms_to_close_tree=t01.get("ms_to_close", trees.get("mean_ms_to_close")),
+                        nodes_per_tree=t01.get("nodes", trees.get("mean_nodes_per_tree"))),
+                    "auto (chosen once at set-up)": dict(
+                        rho=ra["rho"], admm_iter_per_s=ra["value"], nodes_per_s=ra["nodes_per_s"], iters_per_node=ra["iters_per_node"],
+                        ms_to_close_tree=ra["one_tree"]["ms_to_close"], nodes_per_tree=ra["one_tree"]["nodes"],
+                        setup_s=ra["setup_s"])}
         if world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
         print(json.dumps(out))

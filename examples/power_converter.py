@@ -9,7 +9,10 @@ under test; the inputs it applies are checked against the recorded ones step by 
 trajectory), then the reference's statistics are computed: solve-time columns of power_converter_timings.csv,
 switching frequency and current THD.
 
-    python examples/power_converter.py [--backend hip|oracle] [--out results/power_converter_timings.csv]
+    python examples/power_converter.py [--out results/power_converter_timings.csv] [--rho-auto]
+
+(The same replay on the CPU restatement, for side-by-side numbers, is run by tests/side_by_side.py, which hands `run`
+another backend module.)
 """
 import argparse
 import os
@@ -23,12 +26,13 @@ sys.path.insert(0, ROOT)
 from miosqp_amd import harness, problems  # noqa: E402
 
 
-def run(backend_name="hip", steps=None):
-    if backend_name == "oracle":  # CPU restatement, for side-by-side numbers only
-        from oracle import oracle as backend
-    else:
+def run(backend=None, steps=None, rho_auto=False):
+    """backend: a module with the osqp surface (None: miosqp_amd.qp, the HIP engine).  rho_auto: the sequence the reference
+    recorded with rho chosen once at set-up."""
+    if backend is None:
         from miosqp_amd import qp as backend
-    pc = problems.load_power_converter(os.path.join(ROOT, "tests", "golden", "power_converter_N3_long.npz"))
+    pc = problems.load_power_converter(os.path.join(ROOT, "tests", "golden", "power_converter_N3_long_rhoauto.npz" if rho_auto
+                                                    else "power_converter_N3_long.npz"))
     recs, _ = problems.run_power_converter(pc, backend, steps)
     U = np.array([r["x"][:6] for r in recs]).T
     worst = float(np.max(np.abs(U - pc["U"][:, :U.shape[1]])))
@@ -44,10 +48,10 @@ def run(backend_name="hip", steps=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
     ap.add_argument("--out", default=os.path.join(ROOT, "results", "power_converter_timings.csv"))
+    ap.add_argument("--rho-auto", action="store_true", help="the sequence recorded with rho chosen once at set-up")
     args = ap.parse_args()
-    row, pc = run(args.backend)
+    row, pc = run(rho_auto=args.rho_auto)
     cols = ["T", "miosqp_avg", "miosqp_std", "miosqp_min", "miosqp_max", "miosqp_osqp_avg_time",
             "miosqp_avg_osqp_iter", "fsw", "thd"]
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

@@ -8,7 +8,10 @@ of this build).  Times are milliseconds like the reference's (`1e3 * run_time`);
 `t_miosqp_osqp_avg` is the relaxation solver's share of the run time in percent
 (run_example.py:142-143).
 
-    python examples/random_miqp.py [--repeat 10] [--out results/random_miqp.csv] [--backend hip|oracle]
+    python examples/random_miqp.py [--repeat 10] [--out results/random_miqp.csv]
+
+The engine is the only relaxation solver this script knows.  (The same grid on the CPU restatement, for side-by-side
+numbers, is run by tests/side_by_side.py, which hands `main` another backend module.)
 """
 import argparse
 import os
@@ -26,12 +29,12 @@ M_ARR = [5, 100, 25, 200, 50, 200, 100, 300]
 P_ARR = [2, 2, 5, 10, 2, 15, 5, 20]
 
 
-def main():
+def main(argv=None, backend=None):
+    """backend: a module with the osqp surface (None: miosqp_amd.qp, the HIP engine)"""
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeat", type=int, default=10)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "results", "random_miqp.csv"))
-    ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
     ap.add_argument("--concurrent", type=int, default=0,
                     help="K > 0: after the reference's one-at-a-time pass, the `repeat` instances of a shape are set up and "
                          "solved again on K host threads at once (every instance its own engine and stream: the MIQPs of a "
@@ -41,10 +44,7 @@ def main():
     ap.add_argument("--cold", action="store_true",
                     help="do not run the untimed warm-up instance first (the first engine of a process pays ~0.2 s of "
                          "one-time GPU context / code-object loading, which would land in the first grid row)")
-    args = ap.parse_args()
-    backend = None
-    if args.backend == "oracle":  # CPU restatement, for side-by-side numbers only
-        from oracle import oracle as backend
+    args = ap.parse_args(argv)
     if not args.cold:  # one-time process start-up (the CPU analogue is import time), outside every timed instance
         pr = problems.random_miqp(10, 5, 2, density=0.7, seed=12345)
         model = bnb.MIOSQP(backend=backend)

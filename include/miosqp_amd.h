@@ -343,6 +343,13 @@ int miosqp_qp_time_kernel(miosqp_qp_engine *e, int32_t which, int32_t reps, doub
  * of every solve: *ms = total milliseconds, *iters = ADMM iterations executed in them. */
 int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, int32_t reset);
 
+/* Per node of the node-at-a-time search in the host library (miosqp_qp_search_run) since the last reset of the loop
+ * statistics: microseconds of device time per ADMM iteration of a node -- out[0] minimum, out[1] median, out[2] maximum
+ * over the nodes -- and *nodes, how many nodes they are taken over (bench.py prints them next to the mean: a single slow
+ * node cannot move the headline unnoticed).  No reference counterpart: the reference only sums OSQP's run_time
+ * (/root/reference/miosqp/node.py:118). */
+int miosqp_qp_get_node_stats(miosqp_qp_engine *e, double *us_per_iter_min_med_max, int32_t *nodes);
+
 /* Same for solve_batch: *ms device milliseconds in batched chunks, *batch_iters lock-step
  * iterations executed, *node_iters = sum over those iterations of the columns still iterating. */
 int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters,

@@ -646,7 +646,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   e->tpr_pb = pick_tpr((double)f.Pbar.nnz / n);
   e->tpr_pr = pick_tpr((double)f.Praw.nnz / n);
   if (probe_inline) {
-    // rho_once (oracle/qp_oracle.c): RHO_ONCE_ITERS iterations from zero on the set-up's bounds, the rule, a new factor
+    // the rule's recipe: RHO_ONCE_ITERS iterations from zero on the set-up's bounds, the rule, a new factor
     std::vector<double> xs(n), zs(M), ys(M);
     {
       const int big = n > M ? n : M;
@@ -1601,7 +1601,27 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
   if (reset) {
     e->loop_ms = 0.0;
     e->loop_iters = 0;
+    e->node_ms.clear();
+    e->node_it.clear();
   }
+  return 0;
+}
+
+// per node of the hosted search since the last reset of the loop statistics: microseconds of device time per ADMM
+// iteration of a node's launch -- minimum, median, maximum over the nodes -- and the number of nodes they are taken over
+int miosqp_qp_get_node_stats(miosqp_qp_engine *e, double *us_per_iter_min_med_max, int32_t *nodes) {
+  if (!e || !us_per_iter_min_med_max || !nodes) return MIOSQP_EARG;
+  const size_t k = std::min(e->node_ms.size(), e->node_it.size());
+  std::vector<double> v;
+  for (size_t i = 0; i < k; i++)
+    if (e->node_it[i] > 0) v.push_back(1e3 * (double)e->node_ms[i] / (double)e->node_it[i]);
+  *nodes = (int32_t)v.size();
+  us_per_iter_min_med_max[0] = us_per_iter_min_med_max[1] = us_per_iter_min_med_max[2] = 0.0;
+  if (v.empty()) return 0;
+  std::sort(v.begin(), v.end());
+  us_per_iter_min_med_max[0] = v.front();
+  us_per_iter_min_med_max[1] = v[v.size() / 2];
+  us_per_iter_min_med_max[2] = v.back();
   return 0;
 }
 

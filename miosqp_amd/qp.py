@@ -422,6 +422,13 @@ class OSQP(object):
                "get_loop_stats")
         return ms.value, it.value
 
+    def node_stats(self):
+        """(min, median, max) microseconds of device time per ADMM iteration over the nodes of the hosted search since the
+        last loop_stats(reset=True), and the number of nodes."""
+        v, k = np.zeros(3), C.c_int32()
+        _check(self._lib.miosqp_qp_get_node_stats(self._h, _lib.as_d(v), C.byref(k)), "get_node_stats")
+        return float(v[0]), float(v[1]), float(v[2]), k.value
+
     def batch_stats(self, reset=False):
         ms, bi, ni = C.c_double(), C.c_int64(), C.c_int64()
         _check(self._lib.miosqp_qp_get_batch_stats(self._h, C.byref(ms), C.byref(bi), C.byref(ni), int(reset)),

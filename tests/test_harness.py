@@ -66,7 +66,7 @@ def test_power_converter_harness_closes_the_recorded_loop(oracle_mod, tmp_path):
         np.testing.assert_array_equal(r["x"][:6], pc["U"][:, k])
     row = harness.timing_row(3, recs, 200)
     assert row["miosqp_min"] <= row["miosqp_avg"] <= row["miosqp_max"] and 0 < row["miosqp_osqp_avg_time"] <= 100
-    row2, _ = pcx.run("oracle", steps=50)
+    row2, _ = pcx.run(oracle_mod, steps=50)
     assert row2["max_input_deviation"] == 0.0 and "fsw" not in row2
 
 
@@ -74,7 +74,7 @@ def test_random_miqp_csv_schema(tmp_path):
     """examples/random_miqp.py writes the reference's columns (run_example.py:155-216, GUROBI columns aside)."""
     out = str(tmp_path / "grid.csv")
     env = dict(os.environ, PYTHONPATH=ROOT)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "examples", "random_miqp.py"), "--backend", "oracle",
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "side_by_side.py"), "random_miqp",
                            "--repeat", "1", "--out", out], env=env, cwd=ROOT, timeout=600,
                           stdout=subprocess.DEVNULL)
     lines = open(out).read().strip().splitlines()
@@ -90,6 +90,6 @@ def test_power_converter_harness_on_gpu(tmp_path):
     """All 1600 steps on the HIP engine: the loop closes on the recorded inputs, so fsw and THD are the reference's."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import power_converter as pcx
-    row, pc = pcx.run("hip")
+    row, pc = pcx.run()
     assert row["max_input_deviation"] <= 1e-6
     assert abs(row["fsw"] - pc["fsw"]) <= 1e-9 and abs(row["thd"] - pc["thd"]) <= 1e-6
