@@ -229,7 +229,11 @@ typedef struct miosqp_search_info {
 int miosqp_qp_search_create(miosqp_qp_engine *e, int32_t capacity);
 /* new MIQP on the same factor: no leaves, no incumbent */
 int miosqp_qp_search_reset(miosqp_qp_engine *e);
-/* appends a leaf given with explicit vectors (the root, or one from another rank): l_int, u_int (n_int), x0 (n), y0 (M) */
+/* appends a leaf given with explicit vectors (the root, or one from another rank): l_int, u_int (n_int), x0 (n), y0 (M).
+ * Here and in take_leaf / miosqp_qp_stream_add_leaf / _take_leaf / miosqp_qp_pool_write_node / _read_node the four vectors
+ * may live in HOST or in DEVICE memory (unified addressing; the copies are hipMemcpyDefault): between ranks a leaf
+ * travels as one device buffer -- slot store -> RCCL broadcast -> slot store -- and never visits the host
+ * (miosqp_amd/dist.py: ShardedStream; the l <= u check is the host's and is skipped for device memory). */
 int miosqp_qp_search_add_leaf(miosqp_qp_engine *e, const double *l_int, const double *u_int, const double *x0,
                               const double *y0, int32_t depth, double lower);
 /* removes the shallowest open leaf and returns it with explicit vectors; 1 when there is none */

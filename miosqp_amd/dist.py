@@ -156,6 +156,27 @@ class TorchComm(object):
         self.dist.broadcast(buf, src=src)
         return buf.cpu().numpy()
 
+    def leaf_buffer(self, size):
+        """A DEVICE tensor of `size` doubles for leaf records that travel without a host hop (r05), or None when this
+        process has no GPU (the CPU tests over gloo).  One tensor per size, kept: the slot store copies into it device to
+        device, the broadcast sends it (RCCL over xGMI with backend nccl; gloo stages a CUDA tensor itself), the receiving
+        store copies out of it."""
+        t = self.torch
+        if not t.cuda.is_available() or os.environ.get("MIOSQP_LEAF_VIA_HOST") == "1":
+            return None
+        bufs = self.__dict__.setdefault("_leaf_bufs", {})
+        if size not in bufs:
+            try:
+                bufs[size] = t.zeros(size, dtype=t.float64, device=t.device("cuda", t.cuda.current_device()))
+            except RuntimeError:  # (torch's own runtime cannot open the device in this process: the records go via the host)
+                bufs[size] = None
+        return bufs[size]
+
+    def move_tensor(self, buf, src):
+        """the broadcast of move() on a tensor that stays where it is"""
+        self.dist.broadcast(buf, src=src)
+        return buf
+
     def sum(self, arr):
         t = self.torch
         buf = t.tensor(np.asarray(arr, dtype=np.float64), dtype=t.float64, device=self.device)
@@ -544,6 +565,9 @@ class ShardedStream(object):
         self.global_upper = np.inf
         self.global_nodes = self.global_iters = 0
         self.moved = 0
+        self.moved_dev = 0  # leaves received as device tensors (no host hop)
+        # the per-rank search keeps its leaves on a GPU and takes / hands them out by device pointer
+        self._dev_leaves = hasattr(getattr(self.ss, "eng", None), "search_create")
         self.steps = 0
         self._n0 = self._i0 = 0
         self.begin_instance()
@@ -606,12 +630,35 @@ class ShardedStream(object):
         giv = [int(round(v)) for v in tab[:, 1]]
         n, M, p = w.data.n, w.data.m + w.data.n_int, w.data.n_int
         size = 2 * p + n + M + 3
+        # a leaf record = [l_int | u_int | x0 | y0 | depth, lower, valid].  With a GPU under both ends it never visits the
+        # host: the donor's slot store copies the vectors into a device tensor, the tensor is broadcast, the receiver's
+        # store copies them out (three scalars ride in its tail); otherwise (CPU tests, thread communicators) as numpy
+        dev = comm.leaf_buffer(size) if (hasattr(comm, "leaf_buffer") and self._dev_leaves) else None
+        views = None
+        if dev is not None:
+            from miosqp_amd import qp as _qp
+            views = _qp.leaf_record_views(dev, p, n, M)
         for r in range(comm.world):
             if alive_r[r] > 0:
                 continue
             donor = int(np.argmax(giv))
             count = min(self.feed, giv[donor] // 2)
             for _ in range(count):
+                if dev is not None:
+                    if comm.rank == donor:
+                        tail = [0.0, 0.0, 0.0]
+                        if ss.givable() > 0:
+                            rec = ss.give_leaf(into=views)
+                            tail = [float(rec[4]), float(rec[5]), 1.0]
+                            self.moved += 1
+                        dev[-3:] = comm.torch.tensor(tail, dtype=comm.torch.float64)  # (ordered before the broadcast: same stream)
+                    comm.move_tensor(dev, donor)
+                    if comm.rank == r:
+                        tail = dev[-3:].cpu().numpy()  # (waits for the broadcast)
+                        if tail[2] == 1.0:
+                            ss.add_leaf(views[0], views[1], views[2], views[3], int(tail[0]), float(tail[1]))
+                            self.moved_dev += 1
+                    continue
                 msg = None
                 if comm.rank == donor:
                     if ss.givable() > 0:

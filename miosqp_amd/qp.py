@@ -78,6 +78,35 @@ def _f64(a, size, name):
     return a
 
 
+class DevicePtr(object):
+    """`count` doubles at address `addr` of DEVICE memory (a slice of a torch tensor, say): accepted wherever a leaf's
+    vectors go in or come out (search_add_leaf / search_take_leaf, stream_*, pool_write_node / pool_read_node) -- the
+    library copies device to device, a leaf moves between ranks without visiting the host (dist.ShardedStream)."""
+
+    def __init__(self, addr, count):
+        self.addr, self.count = int(addr), int(count)
+
+    def __len__(self):
+        return self.count
+
+
+def leaf_record_views(tensor, n_int, n, m):
+    """DevicePtr views (l_int, u_int, x0, y0) of a device tensor of >= 2 n_int + n + m doubles"""
+    base = tensor.data_ptr()
+    offs = (0, n_int, 2 * n_int, 2 * n_int + n)
+    cnts = (n_int, n_int, n, m)
+    return tuple(DevicePtr(base + 8 * o, c) for o, c in zip(offs, cnts))
+
+
+def _vec(a, size, name):
+    """ctypes pointer of a leaf vector given as an array (host) or a DevicePtr"""
+    if isinstance(a, DevicePtr):
+        if a.count != size:
+            raise ValueError("%s must have %d entries" % (name, size))
+        return C.cast(C.c_void_p(a.addr), _lib.dp)
+    return _lib.as_d(_f64(a, size, name))
+
+
 class OSQP(object):
     def __init__(self):
         self._h = None
@@ -250,17 +279,18 @@ class OSQP(object):
     def search_add_leaf(self, l_int, u_int, x0, y0, depth, lower):
         k = len(l_int)
         rc = _check(self._lib.miosqp_qp_search_add_leaf(
-            self._h, _lib.as_d(_f64(l_int, k, "l_int")), _lib.as_d(_f64(u_int, k, "u_int")),
-            _lib.as_d(_f64(x0, self.n, "x0")), _lib.as_d(_f64(y0, self.m, "y0")), int(depth), float(lower)),
-            "search_add_leaf")
+            self._h, _vec(l_int, k, "l_int"), _vec(u_int, k, "u_int"), _vec(x0, self.n, "x0"), _vec(y0, self.m, "y0"),
+            int(depth), float(lower)), "search_add_leaf")
         if rc == 1:
             raise ValueError("Lower bound must be lower than or equal to upper bound")
 
-    def search_take_leaf(self, n_int):
-        """(l_int, u_int, x0, y0, depth, lower) of the shallowest open leaf, removed from the list; None if none."""
-        l, u, x, y = np.empty(n_int), np.empty(n_int), np.empty(self.n), np.empty(self.m)
+    def search_take_leaf(self, n_int, into=None):
+        """(l_int, u_int, x0, y0, depth, lower) of the shallowest open leaf, removed from the list; None if none.
+        into: four DevicePtr (l_int, u_int, x0, y0) the vectors are copied to instead (device to device)."""
+        l, u, x, y = into if into is not None else (np.empty(n_int), np.empty(n_int), np.empty(self.n), np.empty(self.m))
         depth, lower = C.c_int32(), C.c_double()
-        rc = _check(self._lib.miosqp_qp_search_take_leaf(self._h, _lib.as_d(l), _lib.as_d(u), _lib.as_d(x), _lib.as_d(y),
+        rc = _check(self._lib.miosqp_qp_search_take_leaf(self._h, _vec(l, n_int, "l_int"), _vec(u, n_int, "u_int"),
+                                                         _vec(x, self.n, "x0"), _vec(y, self.m, "y0"),
                                                          C.byref(depth), C.byref(lower)), "search_take_leaf")
         return None if rc == 1 else (l, u, x, y, depth.value, lower.value)
 
@@ -299,16 +329,16 @@ class OSQP(object):
     def stream_add_leaf(self, l_int, u_int, x0, y0, depth, lower):
         k = len(l_int)
         rc = _check(self._lib.miosqp_qp_stream_add_leaf(
-            self._h, _lib.as_d(_f64(l_int, k, "l_int")), _lib.as_d(_f64(u_int, k, "u_int")),
-            _lib.as_d(_f64(x0, self.n, "x0")), _lib.as_d(_f64(y0, self.m, "y0")), int(depth), float(lower)),
-            "stream_add_leaf")
+            self._h, _vec(l_int, k, "l_int"), _vec(u_int, k, "u_int"), _vec(x0, self.n, "x0"), _vec(y0, self.m, "y0"),
+            int(depth), float(lower)), "stream_add_leaf")
         if rc == 1:
             raise ValueError("Lower bound must be lower than or equal to upper bound")
 
-    def stream_take_leaf(self, n_int):
-        l, u, x, y = np.empty(n_int), np.empty(n_int), np.empty(self.n), np.empty(self.m)
+    def stream_take_leaf(self, n_int, into=None):
+        l, u, x, y = into if into is not None else (np.empty(n_int), np.empty(n_int), np.empty(self.n), np.empty(self.m))
         depth, lower = C.c_int32(), C.c_double()
-        rc = _check(self._lib.miosqp_qp_stream_take_leaf(self._h, _lib.as_d(l), _lib.as_d(u), _lib.as_d(x), _lib.as_d(y),
+        rc = _check(self._lib.miosqp_qp_stream_take_leaf(self._h, _vec(l, n_int, "l_int"), _vec(u, n_int, "u_int"),
+                                                         _vec(x, self.n, "x0"), _vec(y, self.m, "y0"),
                                                          C.byref(depth), C.byref(lower)), "stream_take_leaf")
         return None if rc == 1 else (l, u, x, y, depth.value, lower.value)
 
@@ -348,14 +378,18 @@ class OSQP(object):
     def pool_write_node(self, slot, l_int, u_int, x0, y0):
         k = len(l_int)
         rc = _check(self._lib.miosqp_qp_pool_write_node(
-            self._h, int(slot), _lib.as_d(_f64(l_int, k, "l_int")), _lib.as_d(_f64(u_int, k, "u_int")),
-            _lib.as_d(_f64(x0, self.n, "x0")), _lib.as_d(_f64(y0, self.m, "y0"))), "pool_write_node")
+            self._h, int(slot), _vec(l_int, k, "l_int"), _vec(u_int, k, "u_int"), _vec(x0, self.n, "x0"),
+            _vec(y0, self.m, "y0")), "pool_write_node")
         if rc == 1:
             raise ValueError("Lower bound must be lower than or equal to upper bound")
 
-    def pool_read_node(self, slot, n_int, want=("l", "u", "x", "y")):
+    def pool_read_node(self, slot, n_int, want=("l", "u", "x", "y"), into=None):
+        """into: dict of DevicePtr by the same keys: those vectors are copied there (device to device) instead"""
         out = dict(l=np.empty(n_int), u=np.empty(n_int), x=np.empty(self.n), y=np.empty(self.m))
-        ptr = [(_lib.as_d(out[k]) if k in want else None) for k in ("l", "u", "x", "y")]
+        if into:
+            out.update(into)
+        size = dict(l=n_int, u=n_int, x=self.n, y=self.m)
+        ptr = [(_vec(out[k], size[k], k) if k in want else None) for k in ("l", "u", "x", "y")]
         _check(self._lib.miosqp_qp_pool_read_node(self._h, int(slot), *ptr), "pool_read_node")
         return types.SimpleNamespace(**{k: out[k] for k in want})
 

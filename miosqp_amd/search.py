@@ -80,8 +80,9 @@ class HostedSearch(object):
     def givable(self):
         return self._open
 
-    def give_leaf(self):
-        rec = self.eng.search_take_leaf(self.p)
+    def give_leaf(self, into=None):
+        """into: four qp.DevicePtr -- the leaf's vectors stay on the device (dist.ShardedStream)"""
+        rec = self.eng.search_take_leaf(self.p, into)
         info = self.eng.search_run(self.work.settings['tree_explor_rule'], 0)  # (no node: the counts)
         self._open, self._free = info.open_leaves, info.free_slots
         return rec

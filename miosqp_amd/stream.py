@@ -216,13 +216,16 @@ class StreamSearch(object):
         """Open leaves this rank could hand to another one (not yet pushed to the device)."""
         return len(self.open)
 
-    def give_leaf(self):
+    def give_leaf(self, into=None):
         """Takes the shallowest open leaf out of this rank's tree (the largest subtree: keeps the receiver busy
-        longest) and returns it with explicit vectors: (l_int, u_int, x0, y0, depth, lower)."""
+        longest) and returns it with explicit vectors: (l_int, u_int, x0, y0, depth, lower).  into: four qp.DevicePtr the
+        vectors are copied to instead (they stay on the device)."""
         s = self.open.pop_shallowest()
-        nd = self.eng.pool_read_node(s, self.p, want=("l", "u"))
+        d_lu = dict(l=into[0], u=into[1]) if into is not None else None
+        d_xy = dict(x=into[2], y=into[3]) if into is not None else None
+        nd = self.eng.pool_read_node(s, self.p, want=("l", "u"), into=d_lu)
         ws = self.parent[s] if self.parent[s] >= 0 else s  # its warm start: the parent's solution
-        sol = self.eng.pool_read_node(ws, self.p, want=("x", "y"))
+        sol = self.eng.pool_read_node(ws, self.p, want=("x", "y"), into=d_xy)
         rec = (nd.l, nd.u, sol.x, sol.y, int(self.depth[s]), float(self.lower[s]))
         self._done(s)
         return rec
@@ -462,8 +465,8 @@ class NativeStreamSearch(object):
     def givable(self):
         return self._open
 
-    def give_leaf(self):
-        rec = self.eng.stream_take_leaf(self.p)
+    def give_leaf(self, into=None):
+        rec = self.eng.stream_take_leaf(self.p, into)
         self._sync(self.eng.stream_step(self.work.settings['tree_explor_rule'], 1, 0))  # (no round: the counts)
         return rec
 

@@ -30,9 +30,9 @@ def main():
     sh = dist.ShardedStream(model, comm, search=hs, exchange_every=1, ramp_leaves=1, step_kwargs=dict(nodes=2))
     sh.run()
     w = model.work
-    tot = comm.sum([hs.nodes, sh.moved])
+    tot = comm.sum([hs.nodes, sh.moved, sh.moved_dev])
     rec = dict(rank=comm.rank, upper=w.upper_glob, x=list(map(float, w.x)), status=w.status, local_nodes=hs.nodes,
-               nodes_total=float(tot[0]), moved_total=float(tot[1]), gnodes=sh.global_nodes)
+               nodes_total=float(tot[0]), moved_total=float(tot[1]), moved_dev_total=float(tot[2]), gnodes=sh.global_nodes)
     if comm.rank == 0:  # the sequential answer on the same engine form
         ref = bnb.MIOSQP()
         ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st), dict(qs))

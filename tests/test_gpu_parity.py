@@ -1596,6 +1596,57 @@ def test_two_ranks_hosted_search_on_one_device(tmp_path):
         np.testing.assert_array_equal(np.array(r["x"])[ii], np.array(r0["seq_x"])[ii])
     assert recs[0]["local_nodes"] > 0 and recs[1]["local_nodes"] > 0  # both ranks worked
     assert r0["nodes_total"] >= r0["seq_nodes"]
+    # every leaf that changed hands did so as a device tensor: slot store -> broadcast -> slot store, no host hop
+    assert r0["moved_total"] >= 1 and r0["moved_dev_total"] == r0["moved_total"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["hosted", "native_stream", "python_stream"])
+def test_leaves_leave_and_enter_the_slot_store_as_device_tensors(form):
+    """The hand-over dist.ShardedStream uses between ranks, in one process (tests/leaf_dev_worker.py: a process of its own
+    because torch brings its own HIP runtime, which must be the first to open the device): every open leaf of a search is
+    taken out INTO a device tensor (qp.DevicePtr views: the library copies device to device), the tensors are cloned (what
+    a broadcast does), the leaves are put back FROM the clones -- and the search ends where the untouched search ends; the
+    numpy path moves the same bytes."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tr = subprocess.run([sys.executable, os.path.join(root, "tests", "leaf_dev_worker.py"), form], cwd=root,
+                        capture_output=True, text=True, timeout=600)
+    assert tr.returncode == 0 and "leaf round trip ok" in tr.stdout, (tr.stdout[-2000:], tr.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_with_four_ranks_on_one_device_prints_the_line_the_driver_parses(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 4 bench.py --gpus 4 ...` -- the command of the driver's SCALE step --
+    end to end with four processes time-sharing GPU 0 (MIOSQP_BENCH_ONE_DEVICE=1: collectives over gloo; a one-GPU box has
+    no second device for RCCL): rank 0 prints ONE JSON line with the contract's keys, `value` is the whole job's rate,
+    `n_gpus` 4, weak scaling, the headline config, nodes and trees of the sharded hosted search and the per-rank pools of
+    the batched leg.  Not a performance number: four engines share one chip."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MIOSQP_BENCH_ONE_DEVICE="1")
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                         "--gpus", "4", "--steps", "20", "--warmup", "5", "--legs", "batched", "--no-probes",
+                         "--stream-warmup", "40", "--stream-chunks", "40", "--batch-width", "64", "--batch-waves", "2"],
+                        env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert tr.returncode == 0, tr.stderr[-3000:]
+    lines = [ln for ln in tr.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    b = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "nodes_per_s", "nodes", "trees"):
+        assert key in b, key
+    assert b["n_gpus"] == 4 and b["steps"] == 20 and b["warmup"] == 5 and b["scaling"] == "weak" and b["dtype"] == "f64"
+    assert b["higher_is_better"] is True and b["vs_baseline"] is None and b["data"] == "synthetic"
+    assert "random_miqp n=500 m=1000 p=250" in b["metric"] and "BASELINE configs[1]" in b["config"]["workload"]
+    assert "sharded over 4 GPU(s)" in b["config"]["workload"]
+    assert b["value"] > 0 and b["nodes"] >= 20 and b["ms_per_step"] > 0 and b["nodes_per_s"] > 0
+    assert abs(b["value"] - b["nodes_per_s"] * b["iters_per_node"]) <= 0.02 * b["value"]
+    assert b["config"]["comm"].startswith("TorchComm")
+    bt = b["batched"]
+    assert "one pool per rank" in bt["form"] and bt["nodes"] > 0 and 0 < bt["column_occupancy"] <= 1.0
 
 
 @pytest.mark.parametrize("n,m,p,seed,rule", [(30, 150, 15, 4, 1), (50, 100, 25, 2, 1), (20, 40, 10, 1, 0), (100, 150, 40, 7, 1),
