@@ -221,11 +221,11 @@ class StreamSearch(object):
         longest) and returns it with explicit vectors: (l_int, u_int, x0, y0, depth, lower).  into: four qp.DevicePtr the
         vectors are copied to instead (they stay on the device)."""
         s = self.open.pop_shallowest()
-        d_lu = dict(l=into[0], u=into[1]) if into is not None else None
-        d_xy = dict(x=into[2], y=into[3]) if into is not None else None
-        nd = self.eng.pool_read_node(s, self.p, want=("l", "u"), into=d_lu)
+        kw_lu = dict(into=dict(l=into[0], u=into[1])) if into is not None else {}
+        kw_xy = dict(into=dict(x=into[2], y=into[3])) if into is not None else {}
+        nd = self.eng.pool_read_node(s, self.p, want=("l", "u"), **kw_lu)
         ws = self.parent[s] if self.parent[s] >= 0 else s  # its warm start: the parent's solution
-        sol = self.eng.pool_read_node(ws, self.p, want=("x", "y"), into=d_xy)
+        sol = self.eng.pool_read_node(ws, self.p, want=("x", "y"), **kw_xy)
         rec = (nd.l, nd.u, sol.x, sol.y, int(self.depth[s]), float(self.lower[s]))
         self._done(s)
         return rec
