@@ -82,7 +82,7 @@ class HostedSearch(object):
 
     def give_leaf(self, into=None):
         """into: four qp.DevicePtr -- the leaf's vectors stay on the device (dist.ShardedStream)"""
-        rec = self.eng.search_take_leaf(self.p, into)
+        rec = self.eng.search_take_leaf(self.p, into) if into is not None else self.eng.search_take_leaf(self.p)
         info = self.eng.search_run(self.work.settings['tree_explor_rule'], 0)  # (no node: the counts)
         self._open, self._free = info.open_leaves, info.free_slots
         return rec

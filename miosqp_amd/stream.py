@@ -466,7 +466,7 @@ class NativeStreamSearch(object):
         return self._open
 
     def give_leaf(self, into=None):
-        rec = self.eng.stream_take_leaf(self.p, into)
+        rec = self.eng.stream_take_leaf(self.p, into) if into is not None else self.eng.stream_take_leaf(self.p)
         self._sync(self.eng.stream_step(self.work.settings['tree_explor_rule'], 1, 0))  # (no round: the counts)
         return rec
 
