@@ -477,7 +477,7 @@ def rho_auto_leg(prob, cfg, seed, local_rank, nodes, batched_chunks=0):
         del closed[:]
         n2, i2, t2 = ss.nodes, ss.iters, time.perf_counter()
         chunks(batched_chunks)
-        eng.pool_collect(0)
+        ss.step(rounds=-1)  # (the launches in flight: waited for, their digests absorbed and counted)
         torch.cuda.synchronize()
         dts = time.perf_counter() - t2
         sms, sit, snode = eng.batch_stats()
@@ -806,7 +806,10 @@ def main():
         del stream["closed"][:]
         t2 = time.perf_counter()
         stream_steps(args.stream_chunks)
-        eng.pool_collect(0)  # the launch in flight belongs to the timed region (its digests are not counted)
+        if native:
+            ss.step(rounds=-1)  # the launches in flight belong to the timed region: waited for, their digests absorbed and counted
+        else:
+            eng.pool_collect(0)  # (Python driver: the launch in flight belongs to the timed region, its digests are not counted)
         sync()
         dts = time.perf_counter() - t2
         sms, sit, snode = eng.batch_stats()
@@ -867,8 +870,11 @@ def main():
                 mdl.work.solver.batch_stats(reset=True)
             t3 = time.perf_counter()
             mp.steps(args.stream_chunks, reroot)
-            for mdl in mp.models:
-                mdl.work.solver.pool_collect(0)
+            for sh_, mdl in zip(mp.sh, mp.models):
+                if args.stream_driver == "native":
+                    sh_.ss.step(rounds=-1)  # (absorbed and counted, as for the single pool)
+                else:
+                    mdl.work.solver.pool_collect(0)
             torch.cuda.synchronize()
             dtp = time.perf_counter() - t3
             st3 = [mdl.work.solver.batch_stats() for mdl in mp.models]
