@@ -1562,6 +1562,13 @@ static void kernel_bytes(const miosqp_qp_engine *e, double b[6]) {
   // dense G block) carries no index array, so those entries move 8 bytes, not the 12 of the formula above
   b[5] = (e->fold ? 2 * ((double)n * M + nt) * 8 : 2 * (np * 12 + nt * 8)) + rest;
   if (e->pers && e->pp.sinv && e->pp.res_w) b[5] -= n * (n - e->pp.res_c0) * 8;  // columns of S^-1 that stay in LDS
+  if (e->pers && e->pp.sinv && e->pp.sym) {  // the tiles on and above the diagonal instead of the whole of S^-1
+    double tiles = 0;
+    for (int I = 0; I < e->pp.sym_T; I++)
+      for (int J = I; J < e->pp.sym_T; J++)
+        tiles += (double)std::min(e->pp.sym_C, e->n - I * e->pp.sym_C) * std::min(e->pp.sym_C, e->n - J * e->pp.sym_C);
+    b[5] += (tiles - 2 * nt) * 8;
+  }
 }
 
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
@@ -1721,6 +1728,7 @@ int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which) {
     return t->users;
   }
   if (which == 5) return (e->pers_capable && e->pp.sinv && e->pp.res_w) ? e->n - e->pp.res_c0 : 0;
+  if (which == 6) return (e->pers_capable && e->pp.sinv && e->pp.sym) ? e->pp.sym_tiles : 0;
   return which == 0 ? e->compactions : which == 1 ? e->kbp_fallbacks : -1;
 }
 

@@ -487,6 +487,11 @@ class OSQP(object):
         """Columns of every row of S^-1 the persistent streaming solver keeps in LDS for a whole launch (0: none)."""
         return int(self._lib.miosqp_qp_debug_counter(self._h, 5))
 
+    def tail_inverse_tiles(self):
+        """Tiles of S^-1 (on and above the diagonal, one per workgroup) the persistent streaming solver reads per iteration
+        when it takes the matrix as symmetric; 0: it streams whole rows."""
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 6))
+
     def call_off_word(self):
         """The control block's call-off / time-out word once the engine's stream is idle (0: nothing happened)."""
         return int(self._lib.miosqp_qp_debug_counter(self._h, 3))

@@ -1158,6 +1158,7 @@ def test_persistent_solver_with_resident_columns_of_the_tail_inverse(oracle_mod,
     engine without the resident block (MIOSQP_PERS_RESIDENT=0): status, iterations, x, y."""
     from miosqp_amd import qp
     monkeypatch.setenv("MIOSQP_PERS_TEST_SPARSE", "1")
+    monkeypatch.setenv("MIOSQP_PERS_SYM", "0")  # (the row-streaming form of S^-1: the symmetric tiles keep no resident block)
     rng = np.random.RandomState(99)
     seen = 0
     for trial, (n, m, p) in enumerate([(257, 300, 40), (300, 450, 100), (301, 520, 33), (384, 200, 50), (511, 700, 120),
@@ -1188,6 +1189,61 @@ def test_persistent_solver_with_resident_columns_of_the_tail_inverse(oracle_mod,
             g.close()
         assert rel(res[0].x, res[1].x) <= 1e-10
     assert seen >= 5  # (the small ones have no room for a block of 128 columns within half a row)
+
+
+def test_persistent_solver_reads_the_tail_inverse_as_symmetric_tiles(oracle_mod, monkeypatch):
+    """Factor form with the tail as S^-1 (pers = 2), n even: S^-1 is symmetric, and the persistent solver reads only its
+    tiles on and above the diagonal -- one per workgroup, T (T + 1) / 2 of them, half the bytes per iteration --, the row
+    sums of a tile going to the rows' block and its column sums to the columns' block (kernels_pers.inc, pers_sym_rows).
+    Tile edges from 6 to 246 columns (one, two and three 128-column pieces per lane and row, last tile shorter, rows per
+    wave from one to 31), against the oracle where the CPU can afford it and against the same engine streaming whole rows
+    (MIOSQP_PERS_SYM=0): status, iterations, x, y.  Odd n keeps the rows."""
+    from miosqp_amd import qp
+    monkeypatch.setenv("MIOSQP_PERS_RESIDENT", "0")
+    rng = np.random.RandomState(123)
+    pieces = set()
+    for trial, (n, m, p, dens) in enumerate([(130, 300, 20, 0.3), (300, 450, 100, 0.3), (301, 520, 33, 0.3), (384, 200, 50, 0.3),
+                                             (640, 900, 200, 0.3), (900, 300, 60, 0.3), (2600, 700, 100, 0.02), (5400, 300, 40, 0.004)]):
+        pr = problems.random_miqp(n, m, p, density=dens, seed=7100 + trial)
+        A, l, u = problems.extended(pr)
+        M = A.shape[0]
+        x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(M)
+        ro = None
+        if n <= 900:
+            o = oracle_mod.OSQP()
+            o.setup(pr["P"], pr["q"], A, l, u, **problems.QP_SETTINGS)
+            o.warm_start(x=x0, y=y0)
+            ro = o.solve()
+        res = []
+        for sym in ("1", "0"):
+            monkeypatch.setenv("MIOSQP_PERS_SYM", sym)
+            g = qp.OSQP()
+            g.setup(pr["P"], pr["q"], A, l, u, fold=0, resident=0, coop=0, pers=2, **problems.QP_SETTINGS)
+            fs = g.factor_stats()
+            assert fs["pers"] and fs["tail_inverse"], (n, m, p)
+            tiles = g.tail_inverse_tiles()
+            if sym == "1" and n % 2 == 0:
+                G, T = min(256, n // 2), 1  # (one workgroup per CU, at least a pair of variable rows each)
+                while (T + 1) * (T + 2) // 2 <= G:
+                    T += 1
+                C = 2 * ((n + 2 * T - 1) // (2 * T))
+                T = (n + C - 1) // C
+                assert tiles == T * (T + 1) // 2 and tiles <= 256, (n, tiles)
+                pieces.add((C + 14 + 127) // 128)
+            else:
+                assert tiles == 0, (n, sym, tiles)
+            g.warm_start(x=x0, y=y0)
+            rg = g.solve()
+            if ro is not None:
+                assert (rg.info.status_val, rg.info.iter) == (ro.info.status_val, ro.info.iter), (n, m, p, sym)
+                assert rel(rg.x, ro.x) <= SOL_TOL and rel(rg.y, ro.y) <= SOL_TOL, (n, m, p, sym)
+            res.append((rg, fs["bytes_moved_per_iter"]))
+            g.close()
+        assert (res[0][0].info.status_val, res[0][0].info.iter) == (res[1][0].info.status_val, res[1][0].info.iter), (n, m, p)
+        assert rel(res[0][0].x, res[1][0].x) <= 1e-9 and rel(res[0][0].y, res[1][0].y) <= 1e-9, (n, m, p)
+        if n % 2 == 0 and n >= 2000:  # (the dense tail is most of what moves: about half of it is gone)
+            assert res[0][1] < 0.62 * res[1][1], (n, res[0][1], res[1][1])
+    assert pieces == {1, 2, 3}
 
 
 def test_persistent_solver_reports_a_missing_workgroup_and_recovers(monkeypatch):
