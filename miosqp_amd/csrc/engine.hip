@@ -1566,7 +1566,12 @@ static void kernel_bytes(const miosqp_qp_engine *e, double b[6]) {
     double tiles = 0;
     for (int I = 0; I < e->pp.sym_T; I++)
       for (int J = I; J < e->pp.sym_T; J++)
-        tiles += (double)std::min(e->pp.sym_C, e->n - I * e->pp.sym_C) * std::min(e->pp.sym_C, e->n - J * e->pp.sym_C);
+      {
+        const int nr = std::min(e->pp.sym_C, e->n - I * e->pp.sym_C), Rw = (nr + PERS_NW - 1) / PERS_NW;
+        int streamed = 0;  // (every wave keeps the first sym_res rows of its share in LDS)
+        for (int w = 0; w < PERS_NW; w++) streamed += std::max(0, std::min(Rw, nr - w * Rw) - e->pp.sym_res);
+        tiles += (double)streamed * std::min(e->pp.sym_C, e->n - J * e->pp.sym_C);
+      }
     b[5] += (tiles - 2 * nt) * 8;
   }
 }
