@@ -136,7 +136,12 @@ def large_leg(seed, device, nodes=12):
                    moved_frac=round(fs["bytes_moved_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
                    setup_s=round(setup_s, 2))
         if fs["pers"]:
-            rec.update(factor_form=("sparse panels of L + the dense tail as S^-1 = L22^-T D22^-1 L22^-1 (the bytes of the two "
+            tiles = eng.tail_inverse_tiles()
+            rec.update(tail_inverse_tiles=tiles,
+                       factor_form=(("sparse panels of L + the dense tail as S^-1 = L22^-T D22^-1 L22^-1, read as a symmetric matrix: "
+                                     "%d square tiles on and above the diagonal, one per workgroup, half the bytes of the two triangles "
+                                     "(the first rows of every wave's share resident in LDS)" % tiles) if tiles else
+                                    "sparse panels of L + the dense tail as S^-1 = L22^-T D22^-1 L22^-1 (the bytes of the two "
                                     "triangles, one dense phase instead of two)" if fs["tail_inverse"] else
                                     "L (sparse panels + the two triangular sweeps of the pre-inverted tail)") +
                                    ", read from memory every iteration, ONE persistent launch per node (k_pers<false>)",
