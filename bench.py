@@ -167,6 +167,11 @@ def large_leg(seed, device, nodes=12):
                             "rows really request; usec_per_iter: HIP events around the ADMM loops of the timed nodes "
                             "(tests included), usec_back_to_back: iterations only")
             out.update(rec)
+            if rec.get("tail_inverse_tiles"):
+                out["note"] += ("; frac above 1 is not bandwidth above the peak: the kernel reads the symmetric S^-1 = (L22 D22 L22^T)^-1 "
+                                "once per pair (i, j) and without indices -- %.0f MB per iteration where SURVEY 8d's formula counts %.0f MB "
+                                "for the two sweeps of L --, moved_frac is what the memory system delivers"
+                                % (fs["bytes_moved_per_iter"] * 1e-6, fs["bytes_per_iter"] * 1e-6))
             if not fs["pers"]:
                 eng.close()
                 break
