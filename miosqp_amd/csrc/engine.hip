@@ -475,6 +475,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
   HIPCHK(hipGetDevice(&e->device));
   const bool t_on = getenv("MIOSQP_SETUP_TIMING") != nullptr;
   double t_last = wall();
+  const double t_begin = t_last;
   auto tick = [&](const char *what) {
     if (!t_on) return;
     const double now = wall();
@@ -658,7 +659,13 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     tick("rho chosen at set-up: probing iterations + the rule");
     if (rho_new > 0 && rho_new != s->rho) {
       std::string err2;
-      if (!miosqp::build_factor(e->sc, Pp, Pi, Px, rho_new, s->sigma, e->fa, err2, nullptr, nullptr, true)) {
+      // (the dense part on the device -- a third of the host's time at config 2 --, the result back on the host for the
+      //  product form's rows; MIOSQP_RHO_HOST_REFACTOR=1 keeps it on the host)
+      miosqp::DenseAccelCtx actx2;
+      actx2.stream = e->stream;
+      const bool dev2 = !getenv("MIOSQP_RHO_HOST_REFACTOR");
+      if (!miosqp::build_factor(e->sc, Pp, Pi, Px, rho_new, s->sigma, e->fa, err2, dev2 ? miosqp_device_ldl_inverse : nullptr,
+                                dev2 ? &actx2 : nullptr, true)) {
         g_err = err2;
         miosqp_qp_cleanup(e);
         return MIOSQP_EFACTOR;
@@ -882,6 +889,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     if (rc) { miosqp_qp_cleanup(e); return rc; }
   }
   tick("graph capture / calibration");
+  if (t_on) fprintf(stderr, "[miosqp setup] %-32s %8.3f ms\n", "miosqp_qp_setup, all of it", 1e3 * (wall() - t_begin));
   *out = e;
   return 0;
 }
