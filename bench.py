@@ -523,7 +523,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-width", type=int, default=256,
                     help="extra leg: leaves per batched wave (BASELINE configs[2]); 0 = skip")
-    ap.add_argument("--batch-waves", type=int, default=6)
+    ap.add_argument("--batch-waves", type=int, default=6, help="waves of the wave form in the batched leg (0: the stream alone)")
     ap.add_argument("--stream-warmup", type=int, default=700, help="streaming leg: chunks before the timed stretch")
     ap.add_argument("--stream-chunks", type=int, default=600, help="streaming leg: timed chunks")
     ap.add_argument("--pools", type=int, default=2,
@@ -755,29 +755,31 @@ def main():
     #      between chunks, 64-byte digests back: miosqp_amd/stream.py) -------------------------------------
     batched = None
     if "batched" in legs:
-        next_instance()
-        run_steps(6, args.batch_width, True)  # warm-up: graph capture, allocation, frontier ramp-up
-        sync()
-        eng.batch_stats(reset=True)
-        n1, i1 = srch.nodes, srch.iters
-        t1 = time.perf_counter()
-        run_steps(args.batch_waves, args.batch_width, True)
-        srch.drain()
-        sync()
-        dtb = time.perf_counter() - t1
-        bms, bit, bnode = eng.batch_stats()
-        totb = comm.sum([srch.iters - i1, srch.nodes - n1])
-        if td is not None:
-            tb = torch.tensor([dtb], dtype=torch.float64, device=comm.device)
-            td.all_reduce(tb, op=td.ReduceOp.MAX)
-            dtb = float(tb.item())
-        waves = dict(waves=args.batch_waves, nodes=float(totb[1]),
-                     mean_wave=round(float(totb[1]) / max(1, args.batch_waves * world), 1),
-                     node_iters_per_s=round(float(totb[0]) / dtb, 1), nodes_per_s=round(float(totb[1]) / dtb, 2),
-                     lockstep_iters=bit, device_us_per_lockstep_iter=round(1e3 * bms / max(1, bit), 2),
-                     device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
-        waves["end_to_end_over_device"] = round(waves["node_iters_per_s"] /
-                                                max(1.0, waves["device_node_iters_per_s"] * world), 3)
+        waves = None  # (--batch-waves 0: the stream alone, e.g. for a kernel table of that form only)
+        if args.batch_waves > 0:
+            next_instance()
+            run_steps(6, args.batch_width, True)  # warm-up: graph capture, allocation, frontier ramp-up
+            sync()
+            eng.batch_stats(reset=True)
+            n1, i1 = srch.nodes, srch.iters
+            t1 = time.perf_counter()
+            run_steps(args.batch_waves, args.batch_width, True)
+            srch.drain()
+            sync()
+            dtb = time.perf_counter() - t1
+            bms, bit, bnode = eng.batch_stats()
+            totb = comm.sum([srch.iters - i1, srch.nodes - n1])
+            if td is not None:
+                tb = torch.tensor([dtb], dtype=torch.float64, device=comm.device)
+                td.all_reduce(tb, op=td.ReduceOp.MAX)
+                dtb = float(tb.item())
+            waves = dict(waves=args.batch_waves, nodes=float(totb[1]),
+                         mean_wave=round(float(totb[1]) / max(1, args.batch_waves * world), 1),
+                         node_iters_per_s=round(float(totb[0]) / dtb, 1), nodes_per_s=round(float(totb[1]) / dtb, 2),
+                         lockstep_iters=bit, device_us_per_lockstep_iter=round(1e3 * bms / max(1, bit), 2),
+                         device_node_iters_per_s=round(bnode / max(1e-9, bms) * 1e3, 1))
+            waves["end_to_end_over_device"] = round(waves["node_iters_per_s"] /
+                                                    max(1.0, waves["device_node_iters_per_s"] * world), 3)
         # the stream: new MIQP, ramp-up until the columns are busy, then a timed stretch.  With more than one rank
         # every rank streams its own leaf pool and the ranks meet every few chunks (dist.ShardedStream)
         from miosqp_amd import stream as stream_mod

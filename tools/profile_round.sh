@@ -80,6 +80,8 @@ if want batched; then
 export MIOSQP_POOL_NOGRAPH=1
 # ONE pool only (--pools 1): with the two-pool leg in the same table the test kernels' maxima are contention, not the kernel
 prof batched "--steps 20 --warmup 5 --legs batched --no-probes --pools 1" "MIOSQP_POOL_NOGRAPH=1"
+# ... and the stream by itself (no waves of the wave form in the table: what is not the persistent kernel is the stream's own)
+prof batched_stream "--steps 20 --warmup 5 --legs batched --no-probes --pools 1 --batch-waves 0" "MIOSQP_POOL_NOGRAPH=1"
 unset MIOSQP_POOL_NOGRAPH
 fi
 ls -la $O
