@@ -137,6 +137,7 @@ def large_leg(seed, device, nodes=12):
                    setup_s=round(setup_s, 2))
         if fs["pers"]:
             tiles = eng.tail_inverse_tiles()
+            kname = "k_pers<false, true>" if tiles else "k_pers<false, false>"  # (the symmetric form is an instantiation of its own)
             rec.update(tail_inverse_tiles=tiles,
                        factor_form=(("sparse panels of L + the dense tail as S^-1 = L22^-T D22^-1 L22^-1, read as a symmetric matrix: "
                                      "%d square tiles on and above the diagonal, one per workgroup, half the bytes of the two triangles "
@@ -144,11 +145,11 @@ def large_leg(seed, device, nodes=12):
                                     "sparse panels of L + the dense tail as S^-1 = L22^-T D22^-1 L22^-1 (the bytes of the two "
                                     "triangles, one dense phase instead of two)" if fs["tail_inverse"] else
                                     "L (sparse panels + the two triangular sweeps of the pre-inverted tail)") +
-                                   ", read from memory every iteration, ONE persistent launch per node (k_pers<false>)",
-                       kernel="k_pers<false>", launches=r["launches"],
+                                   ", read from memory every iteration, ONE persistent launch per node (%s)" % kname,
+                       kernel=kname, launches=r["launches"],
                        iterations_per_launch=round(r["loop_iters"] / max(1, r["launches"]), 1),
                        usec_per_launch=round(1e3 * r["loop_ms"] / max(1, r["launches"]), 1))
-            tr, src = pmc_traffic("k_pers<false>", "_cfg5")
+            tr, src = pmc_traffic(kname, "_cfg5")
             if tr is not None:
                 rec["pmc_traffic"] = dict(bytes_per_launch=tr, source=src,
                                           hbm_measured_gbs=round(tr / (1e3 * r["loop_ms"] / max(1, r["launches"])) * 1e-3, 1))
