@@ -146,4 +146,4 @@ def test_streaming_form_fractions_can_be_recomputed_from_profiles():
         moved = k["bytes_moved"] / k["iterations_per_launch"]
         assert 0.8 * moved <= per_iter <= 1.6 * moved, (name, per_iter, moved)
         if beyond:
-            assert moved > 2 * 256 * 2 ** 20  # two Infinity Caches' worth per iteration: the counters count HBM here
+            assert moved > 256 * 2 ** 20  # more than the Infinity Cache holds, per iteration (the symmetric tiles: 289 MB at n = 8000)

@@ -28,6 +28,8 @@ prof() {
 if want default; then
 timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 400 python bench.py --steps 999 --legs none > $O/bench_999_nodes.json 2> $O/bench_999.err
+# the driver's command (BENCH_rNN.json): 20 timed nodes after 3
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench_driver_slice.json 2> $O/bench_driver_slice.err
 fi
 
 cd /tmp
