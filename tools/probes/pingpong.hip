@@ -3,6 +3,8 @@
 //   mode 0: agent-scope relaxed atomic store + agent-scope relaxed atomic load  (sc1)
 //   mode 1: plain store + non-temporal load  (served by the XCD's L2; only valid inside one XCD)
 //   mode 2: agent-scope store + non-temporal load
+//   mode 3: plain store (write-through to the XCD's L2) + sc0 load (past the CU's L1, from the XCD's L2): inside one XCD only
+//   mode 4: L2 atomic add without sc1 (executed in the XCD's L2) + sc0 load: a barrier counter inside one XCD
 // hipcc --offload-arch=gfx950 -O3 pingpong.hip -o pingpong
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,11 +16,14 @@ __device__ __forceinline__ unsigned xcc_id() {
 }
 template <int MODE>
 __device__ __forceinline__ void put(unsigned long long *p, unsigned long long v) {
+  if (MODE == 3) { asm volatile("global_store_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"(v) : "memory"); return; }
+  if (MODE == 4) { unsigned long long one = 1; asm volatile("global_atomic_add_x2 %0, %1, off\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"(one) : "memory"); return; }
   if (MODE == 1) *(volatile unsigned long long *)p = v;
   else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int MODE>
 __device__ __forceinline__ unsigned long long get(unsigned long long *p) {
+  if (MODE == 3 || MODE == 4) { unsigned long long v; asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
   if (MODE == 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return __builtin_nontemporal_load(p);
 }
@@ -72,6 +77,11 @@ int main() {
   run<0>("agent store / agent load", 0, 8, slots, out, xcc);
   run<2>("agent store / nt load", 0, 1, slots, out, xcc);
   run<2>("agent store / nt load", 0, 8, slots, out, xcc);
+  run<3>("plain store / sc0 load", 0, 8, slots, out, xcc);
+  run<3>("plain store / sc0 load", 0, 16, slots, out, xcc);
+  run<3>("plain store / sc0 load (cross!)", 0, 1, slots, out, xcc);
+  run<4>("L2 atomic add / sc0 load", 0, 8, slots, out, xcc);
+  run<4>("L2 atomic add / sc0 load (cross!)", 0, 1, slots, out, xcc);
   run<1>("plain store / nt load", 0, 8, slots, out, xcc);
   run<1>("plain store / nt load (cross!)", 0, 1, slots, out, xcc);
   // pointer chase over 64 lines (stride 128 B): agent loads vs nt loads
