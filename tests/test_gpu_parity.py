@@ -1197,9 +1197,9 @@ def test_persistent_solver_reads_the_tail_inverse_as_symmetric_tiles(oracle_mod,
     sums of a tile going to the rows' block and its column sums to the columns' block (kernels_pers.inc, pers_sym_rows).
     Tile edges from 6 to 246 columns (one, two and three 128-column pieces per lane and row, last tile shorter, rows per
     wave from one to 31), against the oracle where the CPU can afford it and against the same engine streaming whole rows
-    (MIOSQP_PERS_SYM=0): status, iterations, x, y.  Odd n keeps the rows."""
+    (MIOSQP_PERS_SYM=0): status, iterations, x, y; the tiles with every wave's first rows resident in LDS (the default) and
+    with every row streamed (MIOSQP_PERS_RESIDENT=0) agree bit for bit.  Odd n keeps the rows."""
     from miosqp_amd import qp
-    monkeypatch.setenv("MIOSQP_PERS_RESIDENT", "0")
     rng = np.random.RandomState(123)
     pieces = set()
     for trial, (n, m, p, dens) in enumerate([(130, 300, 20, 0.3), (300, 450, 100, 0.3), (301, 520, 33, 0.3), (384, 200, 50, 0.3),
@@ -1215,8 +1215,9 @@ def test_persistent_solver_reads_the_tail_inverse_as_symmetric_tiles(oracle_mod,
             o.warm_start(x=x0, y=y0)
             ro = o.solve()
         res = []
-        for sym in ("1", "0"):
+        for sym, keep in (("1", "1"), ("0", "0"), ("1", "0")):
             monkeypatch.setenv("MIOSQP_PERS_SYM", sym)
+            monkeypatch.setenv("MIOSQP_PERS_RESIDENT", keep)
             g = qp.OSQP()
             g.setup(pr["P"], pr["q"], A, l, u, fold=0, resident=0, coop=0, pers=2, **problems.QP_SETTINGS)
             fs = g.factor_stats()
@@ -1241,8 +1242,11 @@ def test_persistent_solver_reads_the_tail_inverse_as_symmetric_tiles(oracle_mod,
             g.close()
         assert (res[0][0].info.status_val, res[0][0].info.iter) == (res[1][0].info.status_val, res[1][0].info.iter), (n, m, p)
         assert rel(res[0][0].x, res[1][0].x) <= 1e-9 and rel(res[0][0].y, res[1][0].y) <= 1e-9, (n, m, p)
-        if n % 2 == 0 and n >= 2000:  # (the dense tail is most of what moves: about half of it is gone)
-            assert res[0][1] < 0.62 * res[1][1], (n, res[0][1], res[1][1])
+        if n % 2 == 0:  # resident rows or not: the same sums in the same order
+            np.testing.assert_array_equal(res[0][0].x, res[2][0].x)
+            np.testing.assert_array_equal(res[0][0].y, res[2][0].y)
+        if n % 2 == 0 and n >= 2000:  # (the dense tail is most of what moves: about half of it is gone, less what stays in LDS)
+            assert res[0][1] < res[2][1] < 0.62 * res[1][1], (n, res[0][1], res[2][1], res[1][1])
     assert pieces == {1, 2, 3}
 
 
