@@ -691,6 +691,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loop_ms, loop_iters = eng.loop_stats()
+    loop_launches = eng.loop_launches() if hasattr(eng, "loop_launches") else 0
     node_us = eng.node_stats() if hasattr(eng, "node_stats") else None  # (min, median, max us per iteration over the nodes, count)
     nodes_here = head.nodes - n0
     tot = comm.sum([head.iters - i0, head.nodes - n0, dt])
@@ -909,12 +910,18 @@ def main():
         fs = eng.factor_stats()
         kern = []
         if fs["coop"]:
-            # one launch of k_coop IS one node relaxation (all its iterations and tests): average launch
-            # from the HIP events around the launches of the timed region
-            launches = max(1, nodes_here)
+            # the cooperative grid stays resident for a whole call of the search (k_coop_run: ONE launch takes node after
+            # node from the host's mailbox; where it cannot, one launch of k_coop IS one node relaxation): average launch
+            # from the HIP events around the launches of the timed region -- a resident launch's time includes the host's
+            # turn-around between its nodes
+            launches = max(1, loop_launches if loop_launches else nodes_here)
+            resident = 0 < loop_launches < nodes_here
             us, by = 1e3 * loop_ms / launches, fs["bytes_per_iter"] * loop_iters / launches
-            kern.append(dict(kernel="k_coop", usec=round(us, 3), bytes=round(by), gbs=round(by / max(us, 1e-9) * 1e-3, 1),
-                             launches=launches, iterations_per_launch=round(loop_iters / launches, 1)))
+            kern.append(dict(kernel="k_coop_run" if resident else "k_coop", usec=round(us, 3), bytes=round(by),
+                             gbs=round(by / max(us, 1e-9) * 1e-3, 1), launches=launches,
+                             nodes_per_launch=round(nodes_here / launches, 1),
+                             usec_per_node=round(1e3 * loop_ms / max(1, nodes_here), 3),
+                             iterations_per_launch=round(loop_iters / launches, 1)))
             it_us, it_bytes = (0.0, 0.0) if args.no_probes else eng.time_kernel(4, 2000)
         elif fs["pers"]:  # likewise one launch per node
             launches = max(1, nodes_here)
@@ -976,7 +983,9 @@ def main():
                                          ("node relaxations for %.1f ms" % args.step_budget_ms) if budget
                                          else "%d node(s)" % args.wave, world),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
-                               factor_form="explicit KKT inverse in registers, cooperative launch per node"
+                               factor_form=("explicit KKT inverse in registers, cooperative grid resident over the nodes of a "
+                                            "search_run call (k_coop_run)" if 0 < loop_launches < nodes_here else
+                                            "explicit KKT inverse in registers, cooperative launch per node")
                                if fs["coop"] else ("product form L^-1" if fs["fold"] else "L") + ", persistent streaming launch per node"
                                if fs["pers"] else "product form L^-1 (2 launches/iteration)" if fs["fold"]
                                else "L (4 launches/iteration)",
@@ -991,7 +1000,9 @@ def main():
             # the timed region is a few dozen nodes on the driver's command: the spread over the nodes travels with the mean
             out["usec_per_iter_over_nodes"] = dict(min=round(node_us[0], 4), median=round(node_us[1], 4), max=round(node_us[2], 4),
                                                    nodes=node_us[3], mean=round(1e3 * loop_ms / max(1, loop_iters), 4),
-                                                   what="device time of a node's launch / its ADMM iterations (HIP events)")
+                                                   what="device time of a node (its launch by HIP events, or -- resident grid -- "
+                                                        "the first tester's wall clock from the node's mail to its record) / "
+                                                        "its ADMM iterations")
         if pyloop is not None:
             out["python_loop"] = pyloop
         if batched is not None and batched["lockstep_iters"] > 0:

@@ -354,6 +354,14 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
  * (/root/reference/miosqp/node.py:118). */
 int miosqp_qp_get_node_stats(miosqp_qp_engine *e, double *us_per_iter_min_med_max, int32_t *nodes);
 
+/* Launches of the hosted search's solver kernel since the last reset of the loop statistics.  A node of
+ * miosqp_qp_search_run is one cooperative launch (k_coop) -- or, where the cooperative grid can stay resident, the whole
+ * call is ONE launch (k_coop_run) that takes its nodes from a mailbox the host writes: the loop
+ * `while can_continue: choose_leaf -> solve -> bound_and_branch` of /root/reference/miosqp/solver.py:85-123 with the
+ * `solve` of /root/reference/miosqp/node.py:96-143 resident on the device between nodes.  bench.py divides the loop's
+ * device time by this count for the kernel's average launch. */
+int miosqp_qp_get_loop_launches(miosqp_qp_engine *e, int64_t *launches);
+
 /* Same for solve_batch: *ms device milliseconds in batched chunks, *batch_iters lock-step
  * iterations executed, *node_iters = sum over those iterations of the columns still iterating. */
 int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_iters,

@@ -105,6 +105,7 @@ SYMBOLS = {
     "miosqp_qp_get_rho": (C.c_int, [C.c_void_p, dp]),
     "miosqp_qp_get_loop_stats": (C.c_int, [C.c_void_p, dp, i64p, C.c_int32]),
     "miosqp_qp_get_node_stats": (C.c_int, [C.c_void_p, dp, ip]),
+    "miosqp_qp_get_loop_launches": (C.c_int, [C.c_void_p, i64p]),
     "miosqp_qp_get_batch_stats": (C.c_int, [C.c_void_p, dp, i64p, i64p, C.c_int32]),
     "miosqp_qp_debug_counter": (C.c_int64, [C.c_void_p, C.c_int32]),
     "miosqp_qp_debug_timeline": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.c_int32,

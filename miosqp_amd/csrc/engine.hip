@@ -191,6 +191,7 @@ struct SearchDigest {  // coherent host memory
   int status, iter, int_inf, nextvar, action, branched, pad;
   int todo;  // 1: the launch only ran the relaxation (or was called off): the host still has to launch the epilogue kernels
   double lower, heur_viol, heur_obj, pri_res, dua_res, obj_val;
+  unsigned long long t0, t1;  // device wall clock (100 MHz): the first tester took the node up / wrote this record (0: not stamped)
   unsigned long long seq;  // written last (release, system scope): the record of node `seq` is complete
 };
 struct SearchArgs {
@@ -339,6 +340,9 @@ int miosqp_qp_cleanup(miosqp_qp_engine *e) {
     if (S->own_block) hipFree(S->own_block);
     for (hipEvent_t ev : S->ev)
       if (ev) hipEventDestroy(ev);
+    for (hipEvent_t ev : S->ev_run)
+      if (ev) hipEventDestroy(ev);
+    if (S->mail_host) hipHostFree(S->mail_host);
     delete S;
   }
   if (e->h_ready) hipHostFree(e->h_ready);
@@ -1621,9 +1625,18 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
   if (reset) {
     e->loop_ms = 0.0;
     e->loop_iters = 0;
+    e->loop_launches = 0;
     e->node_ms.clear();
     e->node_it.clear();
   }
+  return 0;
+}
+
+// launches of the hosted search's solver kernel since the last reset of the loop statistics: one per node, or -- the
+// cooperative grid kept resident (k_coop_run) -- one per miosqp_qp_search_run
+int miosqp_qp_get_loop_launches(miosqp_qp_engine *e, int64_t *launches) {
+  if (!e || !launches) return MIOSQP_EARG;
+  *launches = e->loop_launches;
   return 0;
 }
 

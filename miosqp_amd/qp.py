@@ -463,6 +463,13 @@ class OSQP(object):
         _check(self._lib.miosqp_qp_get_node_stats(self._h, _lib.as_d(v), C.byref(k)), "get_node_stats")
         return float(v[0]), float(v[1]), float(v[2]), k.value
 
+    def loop_launches(self):
+        """Launches of the hosted search's solver kernel since the last loop_stats(reset=True): one per node, or one per
+        search_run where the cooperative grid stays resident (k_coop_run)."""
+        k = C.c_int64()
+        _check(self._lib.miosqp_qp_get_loop_launches(self._h, C.byref(k)), "get_loop_launches")
+        return k.value
+
     def batch_stats(self, reset=False):
         ms, bi, ni = C.c_double(), C.c_int64(), C.c_int64()
         _check(self._lib.miosqp_qp_get_batch_stats(self._h, C.byref(ms), C.byref(bi), C.byref(ni), int(reset)),

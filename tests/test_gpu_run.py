@@ -1,0 +1,138 @@
+"""The hosted search with the cooperative grid RESIDENT for a whole miosqp_qp_search_run (kernels_coop.inc: k_coop_run; the
+host feeds it nodes through a mailbox) against the same search with one cooperative launch per node (MIOSQP_COOP_RUN=0):
+the loop of /root/reference/miosqp/solver.py:85-123 around Node.solve (/root/reference/miosqp/node.py:96-143).  A node is a
+pure function of (l, u, x0, y0) and both forms run the same instructions on the same operands, so everything is compared
+for EQUALITY: nodes, ADMM iterations, incumbent value and vector."""
+import numpy as np
+import pytest
+
+from miosqp_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(pr, rule, run, monkeypatch, max_nodes=10 ** 9, capacity=None, step=None, qp=None):
+    from miosqp_amd import bnb, search
+    monkeypatch.setenv("MIOSQP_COOP_RUN", "1" if run else "0")
+    st = dict(problems.BNB_SETTINGS, tree_explor_rule=rule, device_tree=False)
+    mdl = bnb.MIOSQP()
+    mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
+              dict(problems.QP_SETTINGS, coop=1, resident=0, **(qp or {})))
+    eng = mdl.work.solver
+    assert eng.factor_stats()["coop"] is True
+    hs = search.HostedSearch(mdl, capacity=capacity)
+    eng.loop_stats(reset=True)
+    calls = 0
+    while hs.nodes < max_nodes:
+        calls += 1
+        if hs.step(min(step or 10 ** 9, max_nodes - hs.nodes)) == 0:
+            break
+    ms, iters = eng.loop_stats()
+    out = dict(nodes=hs.nodes, iters=hs.iters, upper=float(mdl.work.upper_glob),
+               x=None if mdl.work.x is None else np.array(mdl.work.x, dtype=float), launches=eng.loop_launches(), calls=calls,
+               loop_iters=iters, loop_ms=ms, node_stats=eng.node_stats(), fallbacks=eng.factor_stats()["coop_fallbacks"],
+               open=hs._open)
+    eng.close()
+    return out
+
+
+def _same(a, b):
+    assert (a["nodes"], a["iters"], a["open"]) == (b["nodes"], b["iters"], b["open"])
+    assert a["upper"] == b["upper"]
+    if a["x"] is None:
+        assert b["x"] is None
+    else:
+        np.testing.assert_array_equal(a["x"], b["x"])
+
+
+@pytest.mark.parametrize("n,m,p,seed,rule", [(120, 200, 60, 3, 1), (150, 300, 40, 5, 0), (200, 150, 100, 9, 1), (96, 100, 30, 1, 1)])
+def test_resident_run_equals_a_launch_per_node(n, m, p, seed, rule, monkeypatch):
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    a = _search(pr, rule, True, monkeypatch, max_nodes=400)
+    b = _search(pr, rule, False, monkeypatch, max_nodes=400)
+    _same(a, b)
+    assert a["fallbacks"] == 0 and b["fallbacks"] == 0
+    # the resident grid: one launch per call of search_run; the other form: one per node
+    assert b["launches"] == b["nodes"]
+    assert a["launches"] == a["calls"] and (a["nodes"] < 3 or a["launches"] < a["nodes"])
+    assert a["loop_iters"] == a["iters"] and a["loop_ms"] > 0
+    # every node of the run carries its own device time (stamps of the first tester)
+    assert a["node_stats"][3] == a["nodes"] and a["node_stats"][0] > 0
+
+
+def test_resident_run_in_pieces_and_with_a_growing_store(monkeypatch):
+    """search_run called for 1, 2, 3 ... nodes at a time (every call its own launch), on a slot store that starts with four
+    slots (it grows through copies on the engine's stream: the run is ended and started again around them)."""
+    pr = problems.random_miqp(120, 200, 60, seed=3)
+    whole = _search(pr, 1, True, monkeypatch, max_nodes=150)
+    for step in (1, 7):
+        pieces = _search(pr, 1, True, monkeypatch, max_nodes=150, capacity=4, step=step)
+        _same(whole, pieces)
+        assert pieces["launches"] >= pieces["calls"]
+
+
+def test_resident_run_at_config2_size(monkeypatch):
+    """BASELINE configs[1] (n=500, m=1000, p=250): the first 60 nodes, resident grid against a launch per node -- and the
+    headline's kernel is the resident one by default."""
+    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
+    a = _search(pr, 1, True, monkeypatch, max_nodes=60)
+    b = _search(pr, 1, False, monkeypatch, max_nodes=60)
+    _same(a, b)
+    assert a["launches"] == 1 and b["launches"] == 60
+    monkeypatch.delenv("MIOSQP_COOP_RUN")
+    from miosqp_amd import bnb, search
+    mdl = bnb.MIOSQP()
+    mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(problems.BNB_SETTINGS),
+              dict(problems.QP_SETTINGS))
+    hs = search.HostedSearch(mdl)
+    mdl.work.solver.loop_stats(reset=True)
+    hs.step(20)
+    assert hs.nodes == 20 and mdl.work.solver.loop_launches() == 1
+
+
+def test_resident_run_with_rho_chosen_at_setup(monkeypatch):
+    """the same with rho="auto" (shorter nodes: the host's turn-around is a larger share of each)"""
+    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
+    a = _search(pr, 1, True, monkeypatch, max_nodes=120, qp=dict(rho="auto"))
+    b = _search(pr, 1, False, monkeypatch, max_nodes=120, qp=dict(rho="auto"))
+    _same(a, b)
+
+
+def test_resident_run_that_is_called_off_touches_nothing(monkeypatch):
+    """Workgroup 1 never shows up (MIOSQP_COOP_DBG=64): the resident grid calls itself off at its registration, the node goes
+    through a launch of its own, which is called off the same way, and the search ends in the multi-kernel form with the
+    result of an engine that never was cooperative."""
+    from miosqp_amd import bnb
+    pr = problems.random_miqp(60, 120, 30, seed=11)
+    st = dict(problems.BNB_SETTINGS, device_tree=False)
+    monkeypatch.setenv("MIOSQP_COOP_RUN", "1")
+    monkeypatch.setenv("MIOSQP_COOP_NAP", "12")
+    monkeypatch.setenv("MIOSQP_COOP_DBG", "64")
+    bad = bnb.MIOSQP()
+    bad.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS, coop=1, resident=0))
+    monkeypatch.delenv("MIOSQP_COOP_DBG")
+    ref = bnb.MIOSQP()
+    ref.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st),
+              dict(problems.QP_SETTINGS, coop=0, resident=0))
+    r0, r1 = ref.solve(), bad.solve()
+    fs = bad.work.solver.factor_stats()
+    assert fs["coop"] is False and fs["coop_fallbacks"] >= 2  # the run, then the node's own launch
+    assert (r1.status, bad.work.iter_num, bad.work.osqp_iter) == (r0.status, ref.work.iter_num, ref.work.osqp_iter)
+    assert r1.upper_glob == r0.upper_glob
+    np.testing.assert_array_equal(r1.x, r0.x)
+
+
+def test_resident_run_with_a_time_budget(monkeypatch):
+    """budget_s is checked between nodes: the call returns with the grid stopped and the search resumable"""
+    from miosqp_amd import bnb, search
+    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=0)
+    mdl = bnb.MIOSQP()
+    mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(problems.BNB_SETTINGS),
+              dict(problems.QP_SETTINGS))
+    hs = search.HostedSearch(mdl)
+    hs.step(10 ** 9, budget=0.004)
+    first = hs.nodes
+    assert 1 <= first <= 12
+    hs.step(10 ** 9, budget=0.004)
+    assert hs.nodes > first

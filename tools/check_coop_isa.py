@@ -95,7 +95,9 @@ def poll_hazards(body):
 def loops(asm):
     out = []
     L = asm.split("\n")
-    starts = [i for i, l in enumerate(L) if re.match(r"^_ZN\S*6k_coopILi\d+ELi\d+ELi\d+ELi\d+ELb[01]EEE\S*:", l)]
+    # the kernels of the launch-per-relaxation form, and the per-node function of the resident run (k_coop_run calls it)
+    starts = [i for i, l in enumerate(L) if re.match(r"^_ZN\S*6k_coopILi\d+ELi\d+ELi\d+ELi\d+ELb[01]EEE\S*:", l)
+              or re.match(r"^_ZN\S*13coop_grid_runILi\d+ELi\d+ELi\d+ELi\d+EEE\S*:", l)]
     for s in starts:
         name = L[s].split(":")[0]
         e = next(i for i in range(s, len(L)) if L[i].startswith(".Lfunc_end"))
