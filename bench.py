@@ -692,6 +692,8 @@ def main():
     dt = time.perf_counter() - t0
     loop_ms, loop_iters = eng.loop_stats()
     loop_launches = eng.loop_launches() if hasattr(eng, "loop_launches") else 0
+    # (which kernel those launches were: the engine says so -- with one node per call a resident launch is also one per node)
+    grid_resident = bool(eng.factor_stats().get("search_grid_resident", False))
     node_us = eng.node_stats() if hasattr(eng, "node_stats") else None  # (min, median, max us per iteration over the nodes, count)
     nodes_here = head.nodes - n0
     tot = comm.sum([head.iters - i0, head.nodes - n0, dt])
@@ -915,7 +917,7 @@ def main():
             # from the HIP events around the launches of the timed region -- a resident launch's time includes the host's
             # turn-around between its nodes
             launches = max(1, loop_launches if loop_launches else nodes_here)
-            resident = 0 < loop_launches < nodes_here
+            resident = grid_resident
             us, by = 1e3 * loop_ms / launches, fs["bytes_per_iter"] * loop_iters / launches
             kern.append(dict(kernel="k_coop_run" if resident else "k_coop", usec=round(us, 3), bytes=round(by),
                              gbs=round(by / max(us, 1e-9) * 1e-3, 1), launches=launches,
@@ -984,7 +986,7 @@ def main():
                                          else "%d node(s)" % args.wave, world),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
                                factor_form=("explicit KKT inverse in registers, cooperative grid resident over the nodes of a "
-                                            "search_run call (k_coop_run)" if 0 < loop_launches < nodes_here else
+                                            "search_run call (k_coop_run)" if grid_resident else
                                             "explicit KKT inverse in registers, cooperative launch per node")
                                if fs["coop"] else ("product form L^-1" if fs["fold"] else "L") + ", persistent streaming launch per node"
                                if fs["pers"] else "product form L^-1 (2 launches/iteration)" if fs["fold"]

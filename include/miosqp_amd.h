@@ -319,7 +319,9 @@ int miosqp_qp_get_scaling(miosqp_qp_engine *e, double *D, double *E, double *c);
  * poll delay (64-clock units); out[8] = bytes per iteration the kernels of the form in use actually request (dense
  * blocks carry no index array: 8 B per entry instead of the formula's 12); out[9] = times the engine fell back from
  * the cooperative form; out[7] bit 17 = the explicit KKT inverse failed its residual check at set-up and the engine
- * iterates with the factor's sweeps instead (see miosqp_qp_get_inverse_guard).  out must hold 10 values. */
+ * iterates with the factor's sweeps instead (see miosqp_qp_get_inverse_guard); bit 18 = launches of the hosted search counted
+ * by miosqp_qp_get_loop_launches since the last reset were launches of the resident grid (one per miosqp_qp_search_run).
+ * out must hold 10 values. */
 int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out);
 
 /* rho in use (differs from settings.rho when settings.rho_auto chose it) */

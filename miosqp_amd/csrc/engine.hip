@@ -786,14 +786,14 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
         e->coop_cus = prop.multiProcessorCount;
         if (wantc && can) {
           // the grid must fit the device with one workgroup per CU: ask the runtime instead of assuming it
-          if (coop_occupancy(rw, coop_pick_cpt(N), N <= 1024 ? 2 : 4) < 1) can = false;
+          if (coop_occupancy(rw, coop_pick_cpt(N), N < 1024 ? 2 : 4) < 1) can = false;
         }
         if (wantc && can) {
           e->coop = true;
           e->coop_capable = true;
           e->coop_rw = rw;
           e->coop_cpt = coop_pick_cpt(N);
-          e->coop_cptf = N <= 1024 ? 2 : 4;
+          e->coop_cptf = N < 1024 ? 2 : 4;
           e->coop_T = T;
           d.coop_mg = M;
           d.ldw = (N + 7) & ~7;
@@ -801,7 +801,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           rc = dalloc(e, &Wd, (size_t)N * d.ldw + 64);
           if (!rc) rc = dalloc(e, &d.coop_tag, 64);
           d.coop_stride = 2 * rw;
-          d.coop_half = 2 * (size_t)((N + 15) & ~15);  // two words per entry, room for either row-block size
+          d.coop_half = 2 * (size_t)((N + 1 + 15) & ~15);  // two words per entry (one more than rows: the testers' decision), room for either row-block size
           if (!rc) rc = dalloc(e, &d.coop_buf, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_chk, 2 * d.coop_half + 64);
           if (!rc) rc = dalloc(e, &d.coop_q, (size_t)(256 + 16) * COOP_QS + 64);
@@ -811,7 +811,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
           if (!rc) rc = dalloc(e, &e->coop_epi, 2 * (size_t)COOP_EPI_ENTRIES + 64);
           {
             // the test on workgroups of its own when the exchange grid leaves enough CUs free
-            d.coop_nt = coop_pick_testers(prop.multiProcessorCount - T);
+            d.coop_nt = coop_decision_slot(N, e->coop_cpt) ? coop_pick_testers(prop.multiProcessorCount - T) : 0;
             coop_pick_lag(e);
           }
           double *Kc = nullptr;
@@ -1600,7 +1600,8 @@ int miosqp_qp_get_factor_stats(miosqp_qp_engine *e, int64_t *out) {
   out[3] = (int64_t)b[4];
   out[4] = e->tpr_pv; out[5] = e->tpr_pc; out[6] = e->tpr_tail; out[7] = (e->fold ? 1 : 0) | (e->resident ? 2 : 0) | (e->setup_on_device ? 4 : 0) | (e->coop ? 8 : 0) |
            (e->pers ? 16 : 0) | ((e->pers && e->pp.sinv) ? 32 : 0) | ((e->pers && e->pp.small) ? 64 : 0) |
-           ((e->d.coop_nap & 0xff) << 8) | (e->kbp ? (1 << 16) : 0) | (e->guard_tripped ? (1 << 17) : 0);
+           ((e->d.coop_nap & 0xff) << 8) | (e->kbp ? (1 << 16) : 0) | (e->guard_tripped ? (1 << 17) : 0) |
+           (e->run_launches > 0 ? (1 << 18) : 0);
   return 0;
 }
 
@@ -1626,6 +1627,7 @@ int miosqp_qp_get_loop_stats(miosqp_qp_engine *e, double *ms, int64_t *iters, in
     e->loop_ms = 0.0;
     e->loop_iters = 0;
     e->loop_launches = 0;
+    e->run_launches = 0;
     e->node_ms.clear();
     e->node_it.clear();
   }

@@ -173,8 +173,13 @@ class TorchComm(object):
         return bufs[size]
 
     def move_tensor(self, buf, src):
-        """the broadcast of move() on a tensor that stays where it is"""
+        """the broadcast of move() on a tensor that stays where it is.  The host returns only when the collective has
+        finished with `buf`: RCCL runs on a stream of its own, torch's current stream merely waits for it, and the next writer
+        of the buffer is the donor's slot store on the ENGINE's stream (give_leaf(into=...)), which is ordered against
+        neither -- without the wait a second leaf of the same exchange could overwrite a record still being sent."""
         self.dist.broadcast(buf, src=src)
+        if getattr(buf, "is_cuda", False):
+            self.torch.cuda.current_stream(buf.device).synchronize()
         return buf
 
     def sum(self, arr):

@@ -436,7 +436,8 @@ class OSQP(object):
                     bytes_per_iter=int(out[3]), bytes_moved_per_iter=int(out[8]), coop_fallbacks=int(out[9]),
                     tpr=(int(out[4]), int(out[5]), int(out[6])),
                     fold=bool(out[7] & 1), resident=bool(out[7] & 2), setup_on_device=bool(out[7] & 4), coop=bool(out[7] & 8), pers=bool(out[7] & 16), tail_inverse=bool(out[7] & 32), pers_small=bool(out[7] & 64), coop_nap=(out[7] >> 8) & 0xff,
-                    batch_pers=bool(out[7] & (1 << 16)), inverse_guard_tripped=bool(out[7] & (1 << 17)))
+                    batch_pers=bool(out[7] & (1 << 16)), inverse_guard_tripped=bool(out[7] & (1 << 17)),
+                    search_grid_resident=bool(out[7] & (1 << 18)))
 
     def rho(self):
         """the rho in use (differs from the setting after rho="auto")"""

@@ -14,9 +14,9 @@ import numpy as np  # noqa: E402
 from miosqp_amd import bnb, problems, search  # noqa: E402
 
 
-def one(rho, run, nodes, seed=0):
+def one(rho, run, nodes, seed=0, shape=None):
     os.environ["MIOSQP_COOP_RUN"] = "1" if run else "0"
-    pr = problems.random_miqp(**problems.CONFIGS["cfg2"], seed=seed)
+    pr = problems.random_miqp(**(shape or problems.CONFIGS["cfg2"]), seed=seed)
     qs = dict(problems.QP_SETTINGS)
     if rho == "auto":
         qs["rho"] = "auto"
