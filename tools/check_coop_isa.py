@@ -95,9 +95,10 @@ def poll_hazards(body):
 def loops(asm):
     out = []
     L = asm.split("\n")
-    # the kernels of the launch-per-relaxation form, and the per-node function of the resident run (k_coop_run calls it)
-    starts = [i for i, l in enumerate(L) if re.match(r"^_ZN\S*6k_coopILi\d+ELi\d+ELi\d+ELi\d+ELb[01]EEE\S*:", l)
-              or re.match(r"^_ZN\S*13coop_grid_runILi\d+ELi\d+ELi\d+ELi\d+EEE\S*:", l)]
+    # the kernels of the launch-per-relaxation form with the test inside the grid, and the functions that hold the exchange
+    # grid of the launches with testers: coop_grid_one (k_coop calls it), coop_grid_run (per node of the resident run)
+    starts = [i for i, l in enumerate(L) if re.match(r"^_ZN\S*6k_coopILi\d+ELi\d+ELi\d+ELi\d+ELb0EEE\S*:", l)
+              or re.match(r"^_ZN\S*13coop_grid_(run|one)ILi\d+ELi\d+ELi\d+ELi\d+EEE\S*:", l)]
     for s in starts:
         name = L[s].split(":")[0]
         e = next(i for i in range(s, len(L)) if L[i].startswith(".Lfunc_end"))
