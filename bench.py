@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (s
 ALL_LEGS = ("batched", "stream", "config5", "config4", "config1", "cpu", "pyloop", "rho_auto")
 
 
-def pmc_traffic(kernel, tag=""):
+def pmc_traffic(kernel, tag="", nodes_per_launch=None):
     """HBM-side bytes per launch of `kernel` from the newest COMMITTED rocprofv3 PMC summary
     profiles/r*_pmc_traffic<tag>.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the
     gfx950 correction); (bytes, file) or (None, None).  Not measured in this run: counters need the profiler."""
@@ -64,6 +64,10 @@ def pmc_traffic(kernel, tag=""):
         kernels = rec["kernels"]
         for name in sorted(kernels):  # template instances are listed as "name<...>"
             if name == kernel or name.startswith(kernel + "<"):
+                if nodes_per_launch is not None and "traffic_bytes_per_node" in kernels[name]:
+                    # (a resident launch is as long as its call: the summary's bytes per NODE x this run's nodes per launch)
+                    return int(round(kernels[name]["traffic_bytes_per_node"] * nodes_per_launch)), \
+                        "profiles/" + os.path.basename(files[-1]) + " (bytes per node x nodes per launch)"
                 return kernels[name]["traffic_bytes"], "profiles/" + os.path.basename(files[-1])
     except Exception:
         pass
@@ -130,10 +134,15 @@ def large_leg(seed, device, nodes=12):
         us = r["usec_per_iter"]
         rec = dict(iters_per_s=round(r["iters"] / r["dt"], 1), nodes_per_s=round(r["nodes"] / r["dt"], 2),
                    usec_per_iter=round(us, 2), usec_back_to_back=round(eng.time_kernel(4, 100)[0], 2),
-                   achieved_gbs=round(fs["bytes_per_iter"] / us * 1e-3, 1),
-                   frac=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
+                   # `frac`: what the memory system DELIVERS against 8 TB/s -- the bytes the kernels request (8 B per entry of the
+                   # dense rows / tiles they read, no index arrays), replaced below by the HBM counters' bytes where a committed
+                   # PMC summary of this device code exists; `frac_sec8d`: SURVEY 8d's formula (12 B per entry of L, two sweeps)
+                   # over the same time -- algorithmic bytes, above 1 for a form that reads fewer
+                   frac=round(fs["bytes_moved_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4), frac_source="bytes requested by the kernels",
                    moved_gbs=round(fs["bytes_moved_per_iter"] / us * 1e-3, 1),
                    moved_frac=round(fs["bytes_moved_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
+                   achieved_gbs_sec8d=round(fs["bytes_per_iter"] / us * 1e-3, 1),
+                   frac_sec8d=round(fs["bytes_per_iter"] / us * 1e-3 / HBM_PEAK_GBS, 4),
                    setup_s=round(setup_s, 2))
         if fs["pers"]:
             tiles = eng.tail_inverse_tiles()
@@ -151,8 +160,11 @@ def large_leg(seed, device, nodes=12):
                        usec_per_launch=round(1e3 * r["loop_ms"] / max(1, r["launches"]), 1))
             tr, src = pmc_traffic(kname, "_cfg5")
             if tr is not None:
-                rec["pmc_traffic"] = dict(bytes_per_launch=tr, source=src,
-                                          hbm_measured_gbs=round(tr / (1e3 * r["loop_ms"] / max(1, r["launches"])) * 1e-3, 1))
+                gbs = tr / (1e3 * r["loop_ms"] / max(1, r["launches"])) * 1e-3
+                rec["pmc_traffic"] = dict(bytes_per_launch=tr, source=src, hbm_measured_gbs=round(gbs, 1),
+                                          bytes_per_iter=round(tr / max(1.0, r["loop_iters"] / max(1, r["launches"]))))
+                rec["frac"] = round(gbs / HBM_PEAK_GBS, 4)
+                rec["frac_source"] = "HBM counters (FETCH_SIZE doubled + WRITE_SIZE per launch, %s) / this run's launch time" % src
         else:
             kern = []
             for k, nm in enumerate(KERNELS):
@@ -164,14 +176,15 @@ def large_leg(seed, device, nodes=12):
                                 (cfg["n"], cfg["m"], cfg["p"], cfg["density"]),
                        nnz_L=fs["nnz_L"], bytes_per_iter=fs["bytes_per_iter"], bytes_moved_per_iter=fs["bytes_moved_per_iter"],
                        bound="hbm",
-                       note="frac uses SURVEY 8d's 12 B per factor entry; moved_frac the 8 B per entry the dense tail "
-                            "rows really request; usec_per_iter: HIP events around the ADMM loops of the timed nodes "
-                            "(tests included), usec_back_to_back: iterations only")
+                       note="frac: bytes the memory system delivers per second / 8 TB/s (see frac_source); frac_sec8d: SURVEY 8d's "
+                            "12 B per factor entry over the same time; moved_frac: the 8 B per entry the dense tail rows / tiles "
+                            "request; usec_per_iter: HIP events around the ADMM loops of the timed nodes (tests included), "
+                            "usec_back_to_back: iterations only")
             out.update(rec)
             if rec.get("tail_inverse_tiles"):
-                out["note"] += ("; frac above 1 is not bandwidth above the peak: the kernel reads the symmetric S^-1 = (L22 D22 L22^T)^-1 "
+                out["note"] += ("; frac_sec8d above 1 is not bandwidth above the peak: the kernel reads the symmetric S^-1 = (L22 D22 L22^T)^-1 "
                                 "once per pair (i, j) and without indices -- %.0f MB per iteration where SURVEY 8d's formula counts %.0f MB "
-                                "for the two sweeps of L --, moved_frac is what the memory system delivers"
+                                "for the two sweeps of L"
                                 % (fs["bytes_moved_per_iter"] * 1e-6, fs["bytes_per_iter"] * 1e-6))
             if not fs["pers"]:
                 eng.close()
@@ -443,6 +456,24 @@ def rho_auto_leg(prob, cfg, seed, local_rank, nodes, batched_chunks=0):
     torch.cuda.synchronize()
     tree = dict(ms_to_close=round(1e3 * (time.perf_counter() - tt), 3), nodes=hs.nodes - n0, iters=hs.iters - i0,
                 closed=bool(alive == 0), upper_glob=float(model.work.upper_glob))
+    # ... and the SAME MIQP under the frozen default rho = 0.1 (an engine of its own, set up and closed here): the pair
+    # `by_rho` quotes for the time to close a tree -- like for like, the optima checked against each other
+    m01 = bnb.MIOSQP()
+    m01.setup(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], prob["i_idx"], prob["i_l"], prob["i_u"], dict(st),
+              dict(problems.QP_SETTINGS, device=local_rank))
+    h01 = search.HostedSearch(m01)
+    torch.cuda.synchronize()
+    tt = time.perf_counter()
+    alive = 1
+    while alive != 0 and time.perf_counter() - tt < 20.0:
+        alive = h01.step(256)
+    torch.cuda.synchronize()
+    tree01 = dict(ms_to_close=round(1e3 * (time.perf_counter() - tt), 3), nodes=h01.nodes, iters=h01.iters,
+                  closed=bool(alive == 0), upper_glob=float(m01.work.upper_glob))
+    m01.work.solver.close()
+    same = dict(what="the seed's own MIQP closed from its root under both settings of rho (same instance, same search rule)",
+                rho_default=tree01, rho_auto=tree,
+                upper_glob_agree=bool(abs(tree01["upper_glob"] - tree["upper_glob"]) <= 1e-3 * max(1.0, abs(tree["upper_glob"]))))
     # the rate over `nodes` node relaxations of the MIQP stream
     reroot()
     left = 20
@@ -466,7 +497,7 @@ def rho_auto_leg(prob, cfg, seed, local_rank, nodes, batched_chunks=0):
     out = dict(what="the headline's search with rho chosen once at setup (rho=\"auto\"), then frozen; opt-in",
                rho=eng.rho(), rho_default=0.1, setup_s=round(t_setup, 3), nodes=dn, value=round(di / dt, 1),
                unit="ADMM iter/s", nodes_per_s=round(dn / dt, 2), iters_per_node=round(di / max(1, dn), 1),
-               ms_per_node=round(1e3 * dt / max(1, dn), 4), one_tree=tree)
+               ms_per_node=round(1e3 * dt / max(1, dn), 4), one_tree=tree, same_miqp=same)
     if batched_chunks > 0:
         # configs[2] with the same rho: the stream on the device-resident leaf pool (the `batched` leg's form), 256 columns
         from miosqp_amd import stream as stream_mod
@@ -682,6 +713,11 @@ def main():
 
     head_steps(args.warmup)
     sync()
+    # (the warm-up's launches of the solver kernel: with the timed ones they are all a `--legs none --no-probes` process
+    #  launches -- what the rocprofv3 kernel table of that command adds up)
+    wu_ms, wu_iters = eng.loop_stats() if hasattr(eng, "loop_stats") else (0.0, 0)
+    wu_launches = eng.loop_launches() if hasattr(eng, "loop_launches") else 0
+    wu_nodes = head.nodes
     eng.loop_stats(reset=True)
     n0, i0, inst0 = head.nodes, head.iters, stream["instances"]
     del stream["closed"][:]
@@ -924,6 +960,18 @@ def main():
                              nodes_per_launch=round(nodes_here / launches, 1),
                              usec_per_node=round(1e3 * loop_ms / max(1, nodes_here), 3),
                              iterations_per_launch=round(loop_iters / launches, 1)))
+            if resident:
+                # a resident launch is as long as the call of the search it serves: the launches of one process differ in
+                # length (warm-up: --warmup nodes, timed region: --steps nodes), so a kernel table's AVERAGE launch says
+                # nothing -- its TOTAL does: every launch of the process (warm-up + timed), their nodes and iterations,
+                # and the fraction they give together
+                tot_us, tot_it = 1e3 * (wu_ms + loop_ms), wu_iters + loop_iters
+                kern[-1]["all_launches_of_the_process"] = dict(
+                    launches=wu_launches + launches, nodes=wu_nodes + nodes_here, iterations=tot_it, usec_total=round(tot_us, 1),
+                    usec_per_node=round(tot_us / max(1, wu_nodes + nodes_here), 3),
+                    frac=round(fs["bytes_per_iter"] * tot_it / max(tot_us, 1e-9) * 1e-3 / HBM_PEAK_GBS, 4),
+                    what="warm-up + timed region (with --legs none --no-probes nothing else launches the kernel): compare "
+                         "usec_total with calls x average of the rocprofv3 kernel table of the same command")
             it_us, it_bytes = (0.0, 0.0) if args.no_probes else eng.time_kernel(4, 2000)
         elif fs["pers"]:  # likewise one launch per node
             launches = max(1, nodes_here)
@@ -945,7 +993,7 @@ def main():
                     kern.append(dict(kernel=nm, usec=round(us, 3), bytes=by, gbs=round(by / us * 1e-3, 1)))
                 it_us, it_bytes = eng.time_kernel(4, 100)
         dom = max(kern, key=lambda d: d["usec"])
-        traffic, tsrc = pmc_traffic(dom["kernel"])
+        traffic, tsrc = pmc_traffic(dom["kernel"], nodes_per_launch=dom.get("nodes_per_launch"))
         # What binds the dominant kernel.  `achieved` / `frac` follow the contract: ALGORITHMIC bytes (SURVEY
         # sec. 8d's per-iteration figure x iterations per launch) over the measured launch time against the HBM
         # peak.  For the cooperative solver those bytes never leave the register file after the first
@@ -1052,12 +1100,15 @@ def main():
                 # both settings of rho side by side at the top level: "ADMM iterations/s" rewards the setting that needs more
                 # iterations per node, nodes/s and the time to close a tree -- the other half of BASELINE's metric -- do not
                 ra = out["rho_auto"]
-                t01 = trees.get("one_tree_after_the_timed_region") or {}
+                t01 = ra["same_miqp"]["rho_default"]
                 out["by_rho"] = {
+                    "same_miqp": dict(instance=problems.instance_digest(prob), upper_glob_agree=ra["same_miqp"]["upper_glob_agree"],
+                                      upper_glob={"0.1": t01["upper_glob"], "auto": ra["one_tree"]["upper_glob"]},
+                                      what="ms_to_close_tree / nodes_per_tree of both settings are of this one MIQP, closed from "
+                                           "its root; the rates are of the MIQP stream of the timed region"),
                     "0.1 (frozen default: `value`)": dict(
                         rho=0.1, admm_iter_per_s=out["value"], nodes_per_s=out["nodes_per_s"], iters_per_node=out["iters_per_node"],
-                        ms_to_close_tree=t01.get("ms_to_close", trees.get("mean_ms_to_close")),
-                        nodes_per_tree=t01.get("nodes", trees.get("mean_nodes_per_tree"))),
+                        ms_to_close_tree=t01["ms_to_close"], nodes_per_tree=t01["nodes"]),
                     "auto (chosen once at set-up)": dict(
                         rho=ra["rho"], admm_iter_per_s=ra["value"], nodes_per_s=ra["nodes_per_s"], iters_per_node=ra["iters_per_node"],
                         ms_to_close_tree=ra["one_tree"]["ms_to_close"], nodes_per_tree=ra["one_tree"]["nodes"],

@@ -374,7 +374,9 @@ int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_it
  * one process take turns with k_coop / k_pers / kbp); 3 -> the control block's call-off word once the engine's stream
  * is idle (blocks); 4 -> engines of this device that take turns; 5 -> columns of every row of the tail's inverse that
  * the persistent streaming solver keeps in LDS for a whole launch (0: none); 6 -> tiles of the tail's inverse the
- * persistent streaming solver reads per iteration when it takes it as a symmetric matrix (0: it reads whole rows) */
+ * persistent streaming solver reads per iteration when it takes it as a symmetric matrix (0: it reads whole rows);
+ * 7 -> launches of the stream's persistent kernel (kbs) the leaf pool has queued, 8 -> chunks queued that way, 9 -> chunks
+ * queued as the chunk graph / kernel by kernel instead (a launch of kbs that is called off leaves its chunks undone: 1) */
 int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which);
 
 /* debug: per-workgroup (start, end) stamps (100 MHz wall clock) of ONE launch of a product-form

@@ -1757,6 +1757,9 @@ int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which) {
   }
   if (which == 5) return (e->pers_capable && e->pp.sinv && e->pp.res_w) ? e->n - e->pp.res_c0 : 0;
   if (which == 6) return (e->pers_capable && e->pp.sinv && e->pp.sym) ? e->pp.sym_tiles : 0;
+  if (which == 7) return e->kbs_launches;
+  if (which == 8) return e->kbs_chunks_run;
+  if (which == 9) return e->graph_chunks_run;
   return which == 0 ? e->compactions : which == 1 ? e->kbp_fallbacks : -1;
 }
 

@@ -484,6 +484,10 @@ class OSQP(object):
         """Times a chunk's persistent launch (kbp) was called off and the engine went back to the launches."""
         return int(self._lib.miosqp_qp_debug_counter(self._h, 1))
 
+    def stream_chunks_by_form(self):
+        """(launches of the stream's persistent kernel kbs, chunks queued through them, chunks queued as the chunk graph)"""
+        return tuple(int(self._lib.miosqp_qp_debug_counter(self._h, k)) for k in (7, 8, 9))
+
     def chip_turn_waits(self):
         """Whole-chip launches on this engine's device that were ordered behind another engine's (they take turns)."""
         return int(self._lib.miosqp_qp_debug_counter(self._h, 2))

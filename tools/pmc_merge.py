@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Merge the FETCH_SIZE and WRITE_SIZE passes (tools/rocpd_pmc.py output) into profiles/rNN_pmc_traffic.json.
 
-    python tools/pmc_merge.py fetch.json write.json "<command line profiled>" > profiles/r01_pmc_traffic.json
+    python tools/pmc_merge.py fetch.json write.json "<command line profiled>" [bench.json] > profiles/r01_pmc_traffic.json
+
+bench.json (optional): the line bench.py printed in the FETCH pass.  A launch of the resident search grid (k_coop_run) is as
+long as the call it serves, so a mean per dispatch says little: with the record's count of nodes over all launches of the
+process the kernel also gets `traffic_bytes_per_node`.
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reads exactly half of the bytes of a wide
 coalesced streaming read, so it is doubled; WRITE_SIZE is taken as is.  Both counters are in KiB.
@@ -36,6 +40,20 @@ def main():
             rec["WRITE_SIZE_KiB"] = round(w["mean"], 3)
         rec["traffic_bytes"] = int(round(1024 * (2 * (f["mean"] if f else 0.0) + (w["mean"] if w else 0.0))))
         out["kernels"][k] = rec
+    if len(sys.argv) > 4:
+        try:
+            line = [ln for ln in open(sys.argv[4]).read().splitlines() if ln.startswith("{")][-1]
+            bench = json.loads(line)
+            for kr in bench["roofline"]["kernels"]:
+                allk = kr.get("all_launches_of_the_process")
+                if not allk:
+                    continue
+                for name, rec in out["kernels"].items():
+                    if name == kr["kernel"] or name.startswith(kr["kernel"] + "<"):
+                        rec["nodes_of_all_dispatches"] = allk["nodes"]
+                        rec["traffic_bytes_per_node"] = int(round(rec["traffic_bytes"] * rec["dispatches"] / max(1, allk["nodes"])))
+        except Exception as ex:  # noqa: BLE001
+            out["bench_record_error"] = repr(ex)
     json.dump(out, sys.stdout, indent=1)
 
 

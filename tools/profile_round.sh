@@ -18,10 +18,10 @@ prof() {
   python $R/tools/rocpd_stats.py $(db /tmp/p_$NAME) "$HDR rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (MI355X, $TAG)" "durations in ns; a traced run is slower than an untraced one: the same command untraced is in bench_${NAME}_untraced.json" > $O/rocprofv3_kernel_stats_$NAME.txt
   timeout 400 python $R/bench.py $ARGS > $O/bench_${NAME}_untraced.json 2> /dev/null
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/p_${NAME}_$C -o c -- python $R/bench.py $ARGS > /dev/null 2> $O/pmc_${NAME}_$C.err
+    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/p_${NAME}_$C -o c -- python $R/bench.py $ARGS > $O/pmc_${NAME}_$C.bench.json 2> $O/pmc_${NAME}_$C.err
     python $R/tools/rocpd_pmc.py $(db /tmp/p_${NAME}_$C) > $O/pmc_${NAME}_$C.json
   done
-  python $R/tools/pmc_merge.py $O/pmc_${NAME}_FETCH_SIZE.json $O/pmc_${NAME}_WRITE_SIZE.json "$HDR python bench.py $ARGS" > $O/pmc_traffic_$NAME.json
+  python $R/tools/pmc_merge.py $O/pmc_${NAME}_FETCH_SIZE.json $O/pmc_${NAME}_WRITE_SIZE.json "$HDR python bench.py $ARGS" $O/pmc_${NAME}_FETCH_SIZE.bench.json > $O/pmc_traffic_$NAME.json
 }
 
 # 1. the line the driver records, and the BASELINE.md node budget (999 nodes)
