@@ -677,8 +677,15 @@ def main():
         iters = property(lambda self: self.hs.iters)
         global_nodes = property(lambda self: self.sh.global_nodes if self.sh else self.hs.nodes - self._g0)
 
+        steps_done = 0
+        idle_steps = 0  # steps in which this rank solved no node (it had no leaf: ran dry between two exchanges)
+
         def step(self):
-            return self.sh.step() if self.sh else self.hs.step(args.wave)
+            before = self.hs.nodes
+            alive = self.sh.step() if self.sh else self.hs.step(args.wave)
+            self.steps_done += 1
+            self.idle_steps += 1 if self.hs.nodes == before else 0
+            return alive
 
         def begin_instance(self):
             self._g0 = self.hs.nodes
@@ -719,6 +726,8 @@ def main():
     wu_launches = eng.loop_launches() if hasattr(eng, "loop_launches") else 0
     wu_nodes = head.nodes
     eng.loop_stats(reset=True)
+    if hosted:
+        head._s0, head._d0 = head.steps_done, head.idle_steps
     n0, i0, inst0 = head.nodes, head.iters, stream["instances"]
     del stream["closed"][:]
     t0 = time.perf_counter()
@@ -733,6 +742,12 @@ def main():
     node_us = eng.node_stats() if hasattr(eng, "node_stats") else None  # (min, median, max us per iteration over the nodes, count)
     nodes_here = head.nodes - n0
     tot = comm.sum([head.iters - i0, head.nodes - n0, dt])
+    # per rank: what it did in the timed region (one row per rank, by all-gather: the collective the search itself uses)
+    per_rank = None
+    if hosted and world > 1:
+        s0, d0 = getattr(head, "_s0", 0), getattr(head, "_d0", 0)
+        per_rank = comm.gather([float(rank), float(head.nodes - n0), float(head.iters - i0), float(head.steps_done - s0),
+                                float(head.idle_steps - d0), float(getattr(head.sh, "moved", 0)), dt])
     if hosted:
         model.work.leaves = []  # the open leaves of this instance live in device slots
     dt_max = dt
@@ -1053,6 +1068,12 @@ def main():
                                                    what="device time of a node (its launch by HIP events, or -- resident grid -- "
                                                         "the first tester's wall clock from the node's mail to its record) / "
                                                         "its ADMM iterations")
+        if per_rank is not None:
+            # the sharded search rank by rank: every rank appears once (the collective reached all of them), what it solved,
+            # and in how many of its steps it had no leaf to solve
+            out["ranks"] = [dict(rank=int(r[0]), nodes=int(r[1]), iters=int(r[2]), steps=int(r[3]), idle_steps=int(r[4]),
+                                 idle_frac=round(r[4] / max(1.0, r[3]), 3), leaves_given=int(r[5]), seconds=round(float(r[6]), 4))
+                            for r in per_rank]
         if pyloop is not None:
             out["python_loop"] = pyloop
         if batched is not None and batched["lockstep_iters"] > 0:

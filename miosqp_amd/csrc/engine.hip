@@ -659,7 +659,7 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
     }
     int rc = miosqp_qp_debug_iterate(e, RHO_ONCE_ITERS, xs.data(), zs.data(), ys.data());
     if (rc) { miosqp_qp_cleanup(e); return rc; }
-    const double rho_new = rho_estimate_host(e->sc, s->rho, xs.data(), zs.data(), ys.data());
+    double rho_new = rho_estimate_host(e->sc, s->rho, xs.data(), zs.data(), ys.data());
     tick("rho chosen at set-up: probing iterations + the rule");
     if (rho_new > 0 && rho_new != s->rho) {
       std::string err2;
@@ -670,9 +670,16 @@ int miosqp_qp_setup(miosqp_qp_engine **out, int32_t n, int32_t M, const int32_t 
       const bool dev2 = !getenv("MIOSQP_RHO_HOST_REFACTOR");
       if (!miosqp::build_factor(e->sc, Pp, Pi, Px, rho_new, s->sigma, e->fa, err2, dev2 ? miosqp_device_ldl_inverse : nullptr,
                                 dev2 ? &actx2 : nullptr, true)) {
-        g_err = err2;
-        miosqp_qp_cleanup(e);
-        return MIOSQP_EFACTOR;
+        // the factor at the chosen rho failed (a pivot, the device): the factor is rebuilt in place, so the one at the
+        // starting rho -- which exists: the probing iterations ran on it -- is built again and the choice is dropped
+        fprintf(stderr, "miosqp: rho chosen at set-up (%g): the factor failed (%s); keeping rho = %g\n", rho_new, err2.c_str(), s->rho);
+        rho_new = s->rho;
+        std::string err3;
+        if (!miosqp::build_factor(e->sc, Pp, Pi, Px, rho_new, s->sigma, e->fa, err3, nullptr, nullptr, true)) {
+          g_err = err3;
+          miosqp_qp_cleanup(e);
+          return MIOSQP_EFACTOR;
+        }
       }
       const miosqp::Factor &f2 = e->fa;  // same patterns, same sizes: copied over the first factor
       HIPCHK(hipMemcpy(const_cast<double *>(d.pv_L), f2.panel_by_var.val.data(), sizeof(double) * f2.panel_by_var.val.size(), hipMemcpyHostToDevice));

@@ -37,7 +37,8 @@ def test_roofline_and_cpu_baseline_objects():
     assert r["bound"] in ("hbm", "exchange-latency") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     if r["bound"] == "exchange-latency":
         # the counter traffic comes from a committed PMC summary OF THE SAME DEVICE CODE (source digest), or not at all
-        assert r["kernel"] == "k_coop" and r["traffic_source"]
+        # (k_coop: one launch per node; k_coop_run, r06: the grid resident over a whole call of the search)
+        assert r["kernel"] in ("k_coop", "k_coop_run") and r["traffic_source"]
         assert ("committed profile" in r["traffic_source"]) == (r["traffic"] is not None)
         assert r["traffic"] is not None or "other device code" in r["traffic_source"]
         assert r["hbm_measured_gbs"] is None or r["hbm_measured_gbs"] < 0.2 * r["achieved"]
@@ -66,6 +67,16 @@ def test_committed_profiles_agree_on_the_dominant_kernel():
     calls = sum(int(r.replace("[early exit]", "").split()[-6]) for r in rows)
     total_ns = sum(float(r.replace("[early exit]", "").split()[-5]) for r in rows)
     avg_ns = total_ns / calls
+    if name == "k_coop_run":
+        # a resident launch is as long as the call of the search it serves (warm-up: 10 nodes, timed region: 150): the
+        # table's TOTAL over the launches of the traced command against the HIP-event total of the same command's record
+        nodes = json.load(open(table.replace("_rocprofv3_kernel_stats_nodes_only.txt", "_bench_nodes_only.json")))
+        allk = nodes["roofline"]["kernels"][0]["all_launches_of_the_process"]
+        assert nodes["roofline"]["kernel"] == name and calls == allk["launches"]
+        assert abs(total_ns * 1e-3 - allk["usec_total"]) <= 0.10 * allk["usec_total"]
+        # ... and the fraction those launches give together is the record's own, within the warm-up's share
+        assert abs(allk["frac"] - nodes["roofline"]["frac"]) <= 0.06 * nodes["roofline"]["frac"]
+        return
     assert abs(avg_ns * 1e-3 - d["roofline"]["usec_per_launch"]) <= 0.10 * d["roofline"]["usec_per_launch"]
 
 
@@ -82,13 +93,22 @@ def test_every_roofline_fraction_can_be_recomputed_from_profiles():
     assert abs(k["bytes"] - bytes_per_iter * k["iterations_per_launch"]) <= 1e-3 * k["bytes"]
     assert abs(d["roofline"]["frac"] - k["bytes"] / k["usec"] * 1e-3 / 8000.0) <= 2e-3
     table = nodes[-1].replace("_bench_nodes_only.json", "_rocprofv3_kernel_stats_nodes_only.txt")
-    rows = [ln.replace("[early exit]", "").split() for ln in open(table) if "k_coop<" in ln]
+    rows = [ln.replace("[early exit]", "").split() for ln in open(table) if "k_coop<" in ln or "k_coop_run<" in ln]
     calls = sum(int(r[-6]) for r in rows)
-    avg_ns = sum(float(r[-5]) for r in rows) / calls
+    total_us = sum(float(r[-5]) for r in rows) * 1e-3
     assert calls >= k["launches"]  # warm-up launches are in the table too
-    assert abs(avg_ns * 1e-3 - k["usec"]) <= 0.10 * k["usec"]
     pmc = json.load(open(nodes[-1].replace("_bench_nodes_only.json", "_pmc_traffic.json")))["kernels"]
-    tr = [v for kk, v in pmc.items() if kk.startswith("k_coop")][0]["traffic_bytes"]
+    if k["kernel"] == "k_coop_run":
+        # resident launches (r06): the table's total is warm-up + timed region; per NODE everything lines up
+        allk = k["all_launches_of_the_process"]
+        assert calls == allk["launches"] and abs(total_us - allk["usec_total"]) <= 0.10 * allk["usec_total"]
+        assert abs(total_us / allk["nodes"] - k["usec_per_node"]) <= 0.10 * k["usec_per_node"]
+        rec = [v for kk, v in pmc.items() if kk.startswith("k_coop_run")][0]
+        assert rec["nodes_of_all_dispatches"] == allk["nodes"]
+        tr = rec["traffic_bytes_per_node"] * k["nodes_per_launch"]
+    else:
+        assert abs(total_us / calls - k["usec"]) <= 0.10 * k["usec"]
+        tr = [v for kk, v in pmc.items() if kk.startswith("k_coop")][0]["traffic_bytes"]
     assert tr < 0.1 * k["bytes"]  # register-resident factor: HBM moves a few percent of the algorithmic bytes
     four = nodes[-1].replace("_bench_nodes_only.json", "_pmc_traffic_cfg5_four_launches.json")
     c5 = json.load(open(four if os.path.exists(four) else nodes[-1].replace("_bench_nodes_only.json", "_pmc_traffic_cfg5.json")))["kernels"]
