@@ -91,3 +91,22 @@ def test_cooperative_exchange_loop_has_no_register_spills():
     for fn in ("coop_grid_runILi512ELi8ELi3ELi4E", "coop_grid_oneILi512ELi8ELi3ELi4E"):
         head = [ln for ln in r.stdout.splitlines() if fn in ln]
         assert head and "scratch accesses 0," in head[0], head
+
+
+def test_every_environment_switch_is_documented():
+    """SWITCHES.md lists every MIOSQP_* variable the library, the Python front and bench.py read -- and none that nobody
+    reads (operability: 48 switches scattered over 16 files with no single place that says what they do)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    csrc = os.path.join(root, "miosqp_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".inc", ".cpp", ".hpp")):
+            read |= set(re.findall(r'getenv(?:_off)?\("(MIOSQP_[A-Z0-9_]+)"', open(os.path.join(csrc, f)).read()))
+    for f in [os.path.join(root, "bench.py")] + [os.path.join(root, "miosqp_amd", g) for g in os.listdir(os.path.join(root, "miosqp_amd"))
+                                                 if g.endswith(".py")]:
+        read |= set(re.findall(r'environ(?:\.get)?[\[(]\s*"(MIOSQP_[A-Z0-9_]+)"', open(f).read()))
+    doc = set(re.findall(r"`(MIOSQP_[A-Z0-9_]+)`", open(os.path.join(root, "SWITCHES.md")).read()))
+    assert read - doc == set(), "read but not documented: %s" % sorted(read - doc)
+    assert doc - read == set(), "documented but never read: %s" % sorted(doc - read)
