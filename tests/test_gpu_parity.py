@@ -1709,6 +1709,34 @@ def test_bench_with_four_ranks_on_one_device_prints_the_line_the_driver_parses(t
     assert "one pool per rank" in bt["form"] and bt["nodes"] > 0 and 0 < bt["column_occupancy"] <= 1.0
 
 
+def test_bench_with_eight_ranks_on_one_device_reports_every_rank(tmp_path):
+    """The driver's SCALE command at its widest -- `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` -- with eight
+    processes time-sharing GPU 0 (collectives over gloo): one line, `n_gpus` 8, and one row per rank in `ranks`: every rank
+    took part in the collectives exactly once per row, the rows' nodes add up to the line's, and no rank sat without a leaf
+    in more than a fifth of its steps (the leaf-sharded search keeps eight ranks fed on config 2's trees).  Not a performance
+    number: eight engines share one chip."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MIOSQP_BENCH_ONE_DEVICE="1")
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                         "--gpus", "8", "--steps", "16", "--warmup", "4", "--legs", "none", "--no-probes"],
+                        env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert tr.returncode == 0, tr.stderr[-3000:]
+    lines = [ln for ln in tr.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 8 and b["steps"] == 16 and b["scaling"] == "weak" and "sharded over 8 GPU(s)" in b["config"]["workload"]
+    rows = b["ranks"]
+    assert sorted(r["rank"] for r in rows) == list(range(8))
+    assert sum(r["nodes"] for r in rows) == int(b["nodes"]) and sum(r["iters"] for r in rows) > 0
+    assert all(r["steps"] == 16 for r in rows)
+    worst = max(r["idle_frac"] for r in rows)
+    print("nodes per rank %s, worst idle fraction %.2f" % ([r["nodes"] for r in rows], worst))
+    assert worst <= 0.2, rows
+
+
 @pytest.mark.parametrize("n,m,p,seed,rule", [(30, 150, 15, 4, 1), (50, 100, 25, 2, 1), (20, 40, 10, 1, 0), (100, 150, 40, 7, 1),
                                               (60, 120, 60, 3, 0)])
 def test_hosted_search_equals_the_python_loop(n, m, p, seed, rule):
