@@ -35,8 +35,11 @@ class LocalComm(object):
         return (value, nleaves, extra)
 
     def complete(self, h, have=None):
-        self.extra = tuple(h[2])
+        self.extra = tuple(h[2][:2])
+        self.aux = [float(h[2][2])] if len(h[2]) > 2 else None
         return h[0], 0, None, h[1]
+
+    aux = None  # per rank: the optional third value of `extra` at the last completed exchange (ShardedStream: leaves it could give)
 
     def leaf_counts(self):
         return None
@@ -69,15 +72,16 @@ class TorchComm(object):
         # per call, and the gathered table comes back into pinned memory the same way: one event wait per exchange
         # instead of two implicit synchronisations and three allocations.
         self._gpu = device.type == "cuda"
-        self._mine_h = torch.empty(4, dtype=torch.float64, pin_memory=self._gpu)
-        self._tab_h = torch.empty(4 * self.world, dtype=torch.float64, pin_memory=self._gpu)
+        self._mine_h = torch.empty(5, dtype=torch.float64, pin_memory=self._gpu)
+        self._tab_h = torch.empty(5 * self.world, dtype=torch.float64, pin_memory=self._gpu)
+        self.aux = None  # per rank: the optional third value of `extra` (ShardedStream: leaves the rank could give away)
         self._ring = []  # device buffers of exchanges in flight (post() may run ahead of complete() by one)
 
     def _bufs(self):
         t = self.torch
         if self._ring:
             return self._ring.pop()
-        return (t.empty(4, dtype=t.float64, device=self.device), t.empty(4 * self.world, dtype=t.float64, device=self.device))
+        return (t.empty(5, dtype=t.float64, device=self.device), t.empty(5 * self.world, dtype=t.float64, device=self.device))
 
     def post(self, value, x, nleaves, extra=(0.0, 0.0)):
         """First half of exchange(): the all-gather of (incumbent value, open-leaf count, nodes and ADMM
@@ -89,6 +93,7 @@ class TorchComm(object):
         if self._gpu and getattr(self, "_h2d", None) is not None:
             self._h2d.synchronize()  # (the copy out of the staging tensor of the previous post: long done, unless posts run ahead)
         h[0], h[1], h[2], h[3] = float(value), float(nleaves), float(extra[0]), float(extra[1])
+        h[4] = float(extra[2]) if len(extra) > 2 else 0.0
         mine.copy_(h, non_blocking=self._gpu)
         if self._gpu:
             self._h2d = self.torch.cuda.Event()
@@ -106,12 +111,13 @@ class TorchComm(object):
         if self._gpu:
             self._tab_h.copy_(allv, non_blocking=True)
             t.cuda.current_stream().synchronize()
-            tab = self._tab_h.numpy().reshape(self.world, 4).copy()
+            tab = self._tab_h.numpy().reshape(self.world, 5).copy()
         else:
-            tab = allv.numpy().reshape(self.world, 4).copy()
+            tab = allv.numpy().reshape(self.world, 5).copy()
         self._ring.append((mine, allv))
         self._counts = [int(round(c)) for c in tab[:, 1]]
         self.extra = (float(tab[:, 2].sum()), float(tab[:, 3].sum()))
+        self.aux = [float(v) for v in tab[:, 4]]
         owner = int(np.argmin(tab[:, 0]))
         best = float(tab[owner, 0])
         total = int(round(tab[:, 1].sum()))
@@ -621,18 +627,27 @@ class ShardedStream(object):
 
     def _exchange(self, alive):
         w, comm, ss = self.work, self.comm, self.ss
-        extra = (ss.nodes - self._n0, ss.iters - self._i0)
+        # (the third value rides along for the feeding plan below: one collective per exchange instead of two)
+        extra = (ss.nodes - self._n0, ss.iters - self._i0, float(ss.givable()))
         self._n0, self._i0 = ss.nodes, ss.iters
-        best, owner, x, total = comm.exchange(w.upper_glob, w.x, alive, self.global_upper, extra)
+        best, owner, x, total = comm.exchange(w.upper_glob, w.x, float(len(ss.open) + ss.in_flight), self.global_upper, extra)
         self.global_nodes += int(round(comm.extra[0]))
         self.global_iters += int(round(comm.extra[1]))
         if x is not None:
             self.global_upper = best
             ss.adopt_incumbent(best, x)
         # leaves for the ranks that ran dry: every rank derives the same plan from the gathered counts
-        tab = comm.gather([float(len(ss.open) + ss.in_flight), float(ss.givable())])
-        alive_r = [int(round(v)) for v in tab[:, 0]]
-        giv = [int(round(v)) for v in tab[:, 1]]
+        # (from the exchange's own table -- counts as of just before this exchange's incumbent was adopted: a leaf the plan
+        #  counts on may have been pruned since, the donor then sends an empty token; a communicator without the third value
+        #  gathers the counts separately)
+        counts, aux = comm.leaf_counts(), getattr(comm, "aux", None)
+        if counts is not None and aux is not None and len(aux) == comm.world:
+            alive_r = [int(v) for v in counts]
+            giv = [int(round(v)) for v in aux]
+        else:
+            tab = comm.gather([float(len(ss.open) + ss.in_flight), float(ss.givable())])
+            alive_r = [int(round(v)) for v in tab[:, 0]]
+            giv = [int(round(v)) for v in tab[:, 1]]
         n, M, p = w.data.n, w.data.m + w.data.n_int, w.data.n_int
         size = 2 * p + n + M + 3
         # a leaf record = [l_int | u_int | x0 | y0 | depth, lower, valid].  With a GPU under both ends it never visits the

@@ -49,6 +49,7 @@ class PoolComm(object):
         return out
 
     extra = (0.0, 0.0)
+    aux = None  # per rank: the optional third value of `extra` at the last completed exchange
 
     def gather(self, vec):
         return np.array(self._all(np.asarray(vec, dtype=np.float64)))
@@ -87,6 +88,7 @@ class PoolComm(object):
     def _decide(self, tab, have):
         self._counts = [int(t[1]) for t in tab]
         self.extra = (float(sum(t[3][0] for t in tab)), float(sum(t[3][1] for t in tab)))
+        self.aux = [float(t[3][2]) if len(t[3]) > 2 else 0.0 for t in tab]
         vals = np.array([t[0] for t in tab])
         owner = int(np.argmin(vals))
         best = float(vals[owner])
