@@ -171,7 +171,9 @@ def test_stream_survives_a_persistent_launch_called_off_mid_stream(driver, monke
     r1 = s.run()
     forms = eng.stream_chunks_by_form()
     assert eng.factor_stats()["batch_pers"]  # (back in the persistent form at the end: the engine tries again after a call-off)
-    assert forms[0] >= 3 and eng.batch_pers_fallbacks() >= 1 and forms[2] >= 1, (forms, eng.batch_pers_fallbacks())
+    # (the launch was called off -- once --, and the stream went on: through the chunk graph for a while, or, when nothing was
+    #  in flight at the next round, straight back in the persistent form)
+    assert forms[0] >= 3 and eng.batch_pers_fallbacks() >= 1, (forms, eng.batch_pers_fallbacks())
     assert r1.status == r0.status == bnb.MI_SOLVED and len(s.free) == s.capacity
     assert abs(r1.upper_glob - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
     np.testing.assert_array_equal(np.round(r1.x[pr["i_idx"]]), np.round(r0.x[pr["i_idx"]]))
