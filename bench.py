@@ -545,7 +545,13 @@ def main():
     ap.add_argument("--step-budget-ms", type=float, default=-1.0,
                     help="with more than one rank a step is 'node relaxations for this long, at least one' "
                          "instead of a fixed count (ranks then meet at the exchange without waiting for the "
-                         "rank that drew the expensive node); -1 = 0.5 + 0.5 log2(ranks) ms, 0 = fixed count (--wave)")
+                         "rank that drew the expensive node); -1 = 1.5 + 0.5 log2(ranks per tree) ms, 0 = fixed count (--wave)")
+    ap.add_argument("--ranks-per-tree", type=int, default=-1,
+                    help="headline with more than one rank: how many ranks share the leaves of ONE tree (incumbent all-gather "
+                         "and leaf hand-over inside that group: a sub-communicator); the groups work on different MIQPs of the "
+                         "stream at the same time.  -1 = 2 when the number of ranks is even, else all of them; 0 = all ranks "
+                         "on one tree.  A tree of config 2 has ~220 nodes: its ramp-up and tail keep 0.87 of two ranks busy "
+                         "and 0.68 of eight (profiles/r06_sim_sharded_hosted.txt)")
     ap.add_argument("--python-loop", action="store_true",
                     help="headline: drive every node from Python (solve_node + bnb.Workspace, vectors over PCIe) instead "
                          "of the C++ host loop on device-resident leaves (miosqp_qp_search_*)")
@@ -612,6 +618,20 @@ def main():
             comm = dist.TorchComm(dev)
     else:
         comm = dist.LocalComm()
+    # ranks per tree: the leaf-sharded search of ONE tree runs inside a group of ranks (its own communicator); the groups take
+    # different MIQPs of the stream.  Every rank creates every group (new_group is collective), in the same order.
+    rpt = args.ranks_per_tree
+    if rpt < 0:
+        rpt = 2 if (world >= 2 and world % 2 == 0) else world
+    if rpt == 0 or rpt > world or world % max(1, rpt) != 0:
+        rpt = world
+    tree_group, tree_comm = rank // max(1, rpt), comm
+    if td is not None and world > 1 and rpt < world:
+        for g in range(world // rpt):
+            members = list(range(g * rpt, (g + 1) * rpt))
+            grp = td.new_group(ranks=members, backend="gloo" if one_dev else "nccl")
+            if g == tree_group:
+                tree_comm = dist.TorchComm(torch.device("cpu") if one_dev else dev, group=grp, ranks=members)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -624,7 +644,8 @@ def main():
     eng = model.work.solver
     srch = dist.ShardedSearch(model, comm)
     m_orig = cfg["m"]
-    rng = np.random.RandomState(args.seed + 12345)
+    # (every rank of a tree group draws the same numbers; the groups draw different ones: different MIQPs of the stream)
+    rng = np.random.RandomState(args.seed + 12345 + 7919 * (tree_group if rpt < world else 0))
     stream = dict(instances=1, closed=[])  # closed: (time, global nodes of that tree) per closed tree
 
     def next_instance(who=None):
@@ -647,7 +668,7 @@ def main():
 
     if args.step_budget_ms < 0:
         import math
-        args.step_budget_ms = 0.5 + 0.5 * math.log2(max(1, world))
+        args.step_budget_ms = 1.5 + 0.5 * math.log2(max(1, rpt))
     budget = 1e-3 * args.step_budget_ms if (world > 1 and args.step_budget_ms > 0) else None
 
     def run_steps(count, width, batched):
@@ -669,7 +690,7 @@ def main():
             if world > 1 or (launched and os.environ.get("MIOSQP_FORCE_EXCHANGE") == "1"):
                 # one leaf per rank ends the replicated start-up (a node-at-a-time rank needs one; dry ranks are fed
                 # at the exchanges)
-                self.sh = dist.ShardedStream(model, comm, search=self.hs, exchange_every=1, ramp_leaves=1,
+                self.sh = dist.ShardedStream(model, tree_comm, search=self.hs, exchange_every=1, ramp_leaves=1,
                                              step_kwargs=dict(nodes=10 ** 9 if budget else args.wave, budget=budget))
             self._g0 = 0
 
@@ -696,6 +717,8 @@ def main():
 
     if hosted:
         head = Head()
+        if rpt < world and tree_group > 0:
+            next_instance(head)  # (the groups start on different MIQPs of the stream; group 0 on the seed's own)
 
         def head_steps(count):
             if head.sh is None:
@@ -747,9 +770,11 @@ def main():
     if hosted and world > 1:
         s0, d0 = getattr(head, "_s0", 0), getattr(head, "_d0", 0)
         per_rank = comm.gather([float(rank), float(head.nodes - n0), float(head.iters - i0), float(head.steps_done - s0),
-                                float(head.idle_steps - d0), float(getattr(head.sh, "moved", 0)), dt])
+                                float(head.idle_steps - d0), float(getattr(head.sh, "moved", 0)), dt, float(tree_group)])
     if hosted:
         model.work.leaves = []  # the open leaves of this instance live in device slots
+    if rpt < world:
+        rng.seed(args.seed + 54321)  # (the legs below run on the WHOLE job's communicator: every rank draws the same MIQPs again)
     dt_max = dt
     if td is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm.device)
@@ -1039,14 +1064,16 @@ def main():
                    nodes_per_s=round(nodes / dt_max, 2), iters_per_node=round(iters / max(1.0, nodes), 1),
                    nodes=nodes, trees=trees,
                    config=dict(workload="%s: random_miqp n=%d m=%d p=%d density %.2f seed %d, "
-                                        "%s per rank per step, leaves sharded over %d GPU(s)" %
+                                        "%s per rank per step, leaves sharded over %d GPU(s)%s" %
                                         ({"cfg1": "BASELINE configs[0]'s shape on the GPU", "cfg2": "BASELINE configs[1]",
                                           "cfg5": "BASELINE configs[4]",
                                           "cfg5x": "not a BASELINE config (configs[4]'s shape beyond the Infinity Cache)"}
                                          [args.config],
                                          cfg["n"], cfg["m"], cfg["p"], cfg["density"], args.seed,
                                          ("node relaxations for %.1f ms" % args.step_budget_ms) if budget
-                                         else "%d node(s)" % args.wave, world),
+                                         else "%d node(s)" % args.wave, world,
+                                         "" if rpt >= world else " -- %d ranks per tree (incumbent exchange and leaf hand-over "
+                                         "inside the group), %d trees of the MIQP stream at a time" % (rpt, world // rpt)),
                                instance=problems.instance_digest(prob), nnz_L=fs["nnz_L"],
                                factor_form=("explicit KKT inverse in registers, cooperative grid resident over the nodes of a "
                                             "search_run call (k_coop_run)" if grid_resident else
@@ -1072,7 +1099,8 @@ def main():
             # the sharded search rank by rank: every rank appears once (the collective reached all of them), what it solved,
             # and in how many of its steps it had no leaf to solve
             out["ranks"] = [dict(rank=int(r[0]), nodes=int(r[1]), iters=int(r[2]), steps=int(r[3]), idle_steps=int(r[4]),
-                                 idle_frac=round(r[4] / max(1.0, r[3]), 3), leaves_given=int(r[5]), seconds=round(float(r[6]), 4))
+                                 idle_frac=round(r[4] / max(1.0, r[3]), 3), leaves_given=int(r[5]), seconds=round(float(r[6]), 4),
+                                 tree_group=int(r[7]))
                             for r in per_rank]
         if pyloop is not None:
             out["python_loop"] = pyloop

@@ -60,11 +60,17 @@ class LocalComm(object):
 class TorchComm(object):
     """torch.distributed process group: backend "nccl" is RCCL on ROCm; "gloo" in CPU tests."""
 
-    def __init__(self, device):
+    def __init__(self, device, group=None, ranks=None):
+        """group / ranks: a sub-group of the job (torch.distributed.new_group) and the global ranks it consists of, in
+        group order -- `rank` and `world` are then the GROUP's (bench.py: a few ranks per tree of the MIQP stream, several
+        trees at a time); None: the whole job."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.device = torch, dist, device
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.group = group
+        self.ranks = list(ranks) if ranks is not None else list(range(dist.get_world_size()))
+        self.rank, self.world = (self.ranks.index(dist.get_rank()), len(self.ranks)) if group is not None else \
+            (dist.get_rank(), dist.get_world_size())
         self.extra = (0.0, 0.0)
         self.n_hint = 0  # length of x for ranks that hold no incumbent yet (set by ShardedSearch)
         # The scalar exchange runs every step: its buffers are made once.  On a GPU the four doubles travel through a
@@ -98,7 +104,7 @@ class TorchComm(object):
         if self._gpu:
             self._h2d = self.torch.cuda.Event()
             self._h2d.record()
-        work = self.dist.all_gather_into_tensor(allv, mine, async_op=True)
+        work = self.dist.all_gather_into_tensor(allv, mine, group=self.group, async_op=True)
         return (work, allv, mine, None if x is None else np.array(x, dtype=np.float64, copy=True))
 
     def complete(self, h, have=None):
@@ -128,7 +134,7 @@ class TorchComm(object):
         n = int(self.n_hint if xsnap is None else len(xsnap))
         buf = t.from_numpy(np.ascontiguousarray(xsnap, dtype=np.float64)).to(self.device) \
             if self.rank == owner else t.empty(n, dtype=t.float64, device=self.device)
-        self.dist.broadcast(buf, src=owner)
+        self.dist.broadcast(buf, src=self.ranks[owner], group=self.group)
         return best, owner, buf.cpu().numpy(), total
 
     def exchange(self, value, x, nleaves, have=None, extra=(0.0, 0.0)):
@@ -140,7 +146,7 @@ class TorchComm(object):
         t = self.torch
         mine = t.tensor(np.asarray(vec, dtype=np.float64), dtype=t.float64, device=self.device)
         allv = t.empty(self.world * mine.numel(), dtype=t.float64, device=self.device)
-        self.dist.all_gather_into_tensor(allv, mine)
+        self.dist.all_gather_into_tensor(allv, mine, group=self.group)
         return allv.cpu().numpy().reshape(self.world, -1)
 
     def incumbent(self, value, x):
@@ -159,7 +165,7 @@ class TorchComm(object):
             buf = self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
         else:
             buf = self.torch.empty(size, dtype=self.torch.float64, device=self.device)
-        self.dist.broadcast(buf, src=src)
+        self.dist.broadcast(buf, src=self.ranks[src], group=self.group)
         return buf.cpu().numpy()
 
     def leaf_buffer(self, size):
@@ -183,7 +189,7 @@ class TorchComm(object):
         finished with `buf`: RCCL runs on a stream of its own, torch's current stream merely waits for it, and the next writer
         of the buffer is the donor's slot store on the ENGINE's stream (give_leaf(into=...)), which is ordered against
         neither -- without the wait a second leaf of the same exchange could overwrite a record still being sent."""
-        self.dist.broadcast(buf, src=src)
+        self.dist.broadcast(buf, src=self.ranks[src], group=self.group)
         if getattr(buf, "is_cuda", False):
             self.torch.cuda.current_stream(buf.device).synchronize()
         return buf
@@ -191,11 +197,11 @@ class TorchComm(object):
     def sum(self, arr):
         t = self.torch
         buf = t.tensor(np.asarray(arr, dtype=np.float64), dtype=t.float64, device=self.device)
-        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
         return buf.cpu().numpy()
 
     def barrier(self):
-        self.dist.barrier()
+        self.dist.barrier(group=self.group)
 
 
 class ShardedSearch(object):

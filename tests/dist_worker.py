@@ -25,6 +25,37 @@ def main():
     st = dict(problems.BNB_SETTINGS)
     model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
                 dict(problems.QP_SETTINGS))
+    if os.environ.get("MIOSQP_WORKER_MODE") == "groups":
+        # bench.py's --ranks-per-tree: the job split into groups of `per_rank` ranks, each group a communicator of its own
+        # (dist.TorchComm(group=, ranks=)) closing ITS OWN MIQP with dist.ShardedStream over the hosted search (CPU emulation)
+        import digest_backend
+        from miosqp_amd import search
+        rpt, world, rank = per_rank, td.get_world_size(), td.get_rank()
+        mine = None
+        for g in range(world // rpt):
+            members = list(range(g * rpt, (g + 1) * rpt))
+            grp = td.new_group(ranks=members, backend="gloo")
+            if rank in members:
+                mine = (g, dist.TorchComm(torch.device("cpu"), group=grp, ranks=members))
+        g, gcomm = mine
+        pr = problems.random_miqp(n, m, p, seed=seed + g)  # (a different MIQP per group)
+        model = bnb.MIOSQP(backend=digest_backend)
+        model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                    dict(st, max_iter_bb=10 ** 6), dict(problems.QP_SETTINGS))
+        hs = search.HostedSearch(model, capacity=512)
+        s = dist.ShardedStream(model, gcomm, search=hs, step_kwargs=dict(nodes=2), exchange_every=1, ramp_leaves=1, feed=4)
+        s.run()
+        w = model.work
+        tot = comm.sum([hs.nodes, s.moved])        # the whole job's communicator still works beside the groups'
+        gtot = gcomm.sum([hs.nodes])
+        rec = dict(rank=rank, group=g, group_rank=gcomm.rank, group_world=gcomm.world, upper=w.upper_glob, x=list(map(float, w.x)),
+                   status=w.status, nodes_total=float(tot[0]), group_nodes=float(gtot[0]), gnodes=s.global_nodes, local=hs.nodes,
+                   alive=s.total_alive)
+        with open("%s.%d" % (out_path, rank), "w") as f:
+            json.dump(rec, f)
+        td.barrier()
+        td.destroy_process_group()
+        return
     if os.environ.get("MIOSQP_WORKER_MODE") == "stream":
         # dist.ShardedStream with the CPU emulation of the leaf-pool calls (tests/digest_backend.py)
         import digest_backend

@@ -94,3 +94,34 @@ def test_local_comm_is_the_sequential_search(oracle_mod):
     assert b.work.status == ra.status and b.work.upper_glob == ra.upper_glob
     np.testing.assert_array_equal(b.work.x, ra.x)
     assert s.nodes == a.work.iter_num - 1 and s.iters == a.work.osqp_iter
+
+
+def test_four_ranks_in_two_tree_groups(tmp_path, oracle_mod):
+    """bench.py's --ranks-per-tree (r06): four processes over gloo split into two groups of two ranks, each group a
+    communicator of its own (dist.TorchComm(group=, ranks=)) that closes ITS OWN MIQP with the leaf-sharded hosted search
+    (incumbent all-gather, broadcast of x by the owner's GLOBAL rank, leaf hand-over -- all inside the group) while the other
+    group does the same on another MIQP; the whole job's communicator still works beside them.  Each group ends with the
+    sequential optimum of its own instance."""
+    out = str(tmp_path / "res.json")
+    n, m, p, seed = 30, 150, 15, 4
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MIOSQP_WORKER_MODE="groups")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(m), str(p), str(seed), "2"]
+    subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=900)
+    recs = [json.load(open("%s.%d" % (out, r))) for r in range(4)]
+    assert [r["group"] for r in recs] == [0, 0, 1, 1] and [r["group_rank"] for r in recs] == [0, 1, 0, 1]
+    assert all(r["group_world"] == 2 and r["status"] == bnb.MI_SOLVED and r["alive"] == 0 for r in recs)
+    assert recs[0]["nodes_total"] == sum(r["local"] for r in recs)                 # the job's all-reduce saw all four
+    for g in (0, 1):
+        a, b = recs[2 * g], recs[2 * g + 1]
+        assert a["group_nodes"] == b["group_nodes"] == a["local"] + b["local"]        # the group's saw its two
+        assert a["upper"] == b["upper"] and a["x"] == b["x"] and a["gnodes"] == b["gnodes"]
+        pr = problems.random_miqp(n, m, p, seed=seed + g)
+        model = bnb.MIOSQP(backend=oracle_mod)
+        model.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+                    dict(problems.BNB_SETTINGS), dict(problems.QP_SETTINGS))
+        res = model.solve()
+        assert abs(a["upper"] - res.upper_glob) <= 1e-3 * max(1.0, abs(res.upper_glob))
+        np.testing.assert_array_equal(np.asarray(a["x"])[pr["i_idx"]], res.x[pr["i_idx"]])
+    assert recs[0]["upper"] != recs[2]["upper"]  # (two different MIQPs)

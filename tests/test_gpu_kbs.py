@@ -102,10 +102,10 @@ SHAPES = [(257, 300, 60, 64), (300, 411, 77, 128), (333, 500, 101, 256), (384, 6
 
 @pytest.mark.parametrize("n,m,p,cols", SHAPES)
 def test_persistent_stream_on_odd_shapes(n, m, p, cols, monkeypatch):
-    """a dozen shapes inside kbs's limits (256 <= n <= 512, m + p <= 1024, n + m + p <= 1536; odd and even sizes, column
-    counts below the full 256): the first nodes of each stream through both forms"""
-    if m + p > 1024 or n + m + p > 1536:
-        pytest.skip("outside the persistent sweeps' limits")
+    """a dozen shapes inside kbs's limits (256 <= n <= 512, m <= 1024 general rows -- the integer bound rows are not in the
+    products --, n + m <= 1536; odd and even sizes, column counts below the full 256): the first nodes of each stream through
+    both forms"""
+    assert m <= 1024 and n + m <= 1536
     monkeypatch.setenv("MIOSQP_KBP_MIN_COLS", "1")  # (below 192 columns the engine prefers the launches by itself)
     pr = problems.random_miqp(n, m, p, seed=1000 + n)
     a = _record_stream(pr, cols, True, monkeypatch, 150, read_every=5)

@@ -1730,6 +1730,9 @@ def test_bench_with_eight_ranks_on_one_device_reports_every_rank(tmp_path):
     assert b["n_gpus"] == 8 and b["steps"] == 16 and b["scaling"] == "weak" and "sharded over 8 GPU(s)" in b["config"]["workload"]
     rows = b["ranks"]
     assert sorted(r["rank"] for r in rows) == list(range(8))
+    # two ranks per tree by default: four trees of the MIQP stream at a time, each group with a communicator of its own
+    assert [r["tree_group"] for r in sorted(rows, key=lambda r: r["rank"])] == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert "2 ranks per tree" in b["config"]["workload"] and "4 trees of the MIQP stream at a time" in b["config"]["workload"]
     assert sum(r["nodes"] for r in rows) == int(b["nodes"]) and sum(r["iters"] for r in rows) > 0
     assert all(r["steps"] == 16 for r in rows)
     worst = max(r["idle_frac"] for r in rows)
