@@ -376,7 +376,9 @@ int miosqp_qp_get_batch_stats(miosqp_qp_engine *e, double *ms, int64_t *batch_it
  * the persistent streaming solver keeps in LDS for a whole launch (0: none); 6 -> tiles of the tail's inverse the
  * persistent streaming solver reads per iteration when it takes it as a symmetric matrix (0: it reads whole rows);
  * 7 -> launches of the stream's persistent kernel (kbs) the leaf pool has queued, 8 -> chunks queued that way, 9 -> chunks
- * queued as the chunk graph / kernel by kernel instead (a launch of kbs that is called off leaves its chunks undone: 1) */
+ * queued as the chunk graph / kernel by kernel instead (a launch of kbs that is called off leaves its chunks undone: 1);
+ * 10 -> the poll delay the resident search grid ran with last (-1: it has not run), 11 -> synthetic nodes the calibration of
+ * that delay has run on this engine (0: looked up) */
 int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which);
 
 /* debug: per-workgroup (start, end) stamps (100 MHz wall clock) of ONE launch of a product-form

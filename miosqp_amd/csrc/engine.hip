@@ -1767,6 +1767,8 @@ int64_t miosqp_qp_debug_counter(miosqp_qp_engine *e, int32_t which) {
   if (which == 7) return e->kbs_launches;
   if (which == 8) return e->kbs_chunks_run;
   if (which == 9) return e->graph_chunks_run;
+  if (which == 10) return e->run_nap_in_use;
+  if (which == 11) return e->run_cal_nodes;
   return which == 0 ? e->compactions : which == 1 ? e->kbp_fallbacks : -1;
 }
 

@@ -488,6 +488,10 @@ class OSQP(object):
         """(launches of the stream's persistent kernel kbs, chunks queued through them, chunks queued as the chunk graph)"""
         return tuple(int(self._lib.miosqp_qp_debug_counter(self._h, k)) for k in (7, 8, 9))
 
+    def resident_grid_poll_delay(self):
+        """(poll delay the resident search grid ran with last, or -1; synthetic nodes its calibration ran on this engine)"""
+        return int(self._lib.miosqp_qp_debug_counter(self._h, 10)), int(self._lib.miosqp_qp_debug_counter(self._h, 11))
+
     def chip_turn_waits(self):
         """Whole-chip launches on this engine's device that were ordered behind another engine's (they take turns)."""
         return int(self._lib.miosqp_qp_debug_counter(self._h, 2))

@@ -136,3 +136,37 @@ def test_resident_run_with_a_time_budget(monkeypatch):
     assert 1 <= first <= 12
     hs.step(10 ** 9, budget=0.004)
     assert hs.nodes > first
+
+
+def test_resident_run_calibrates_its_poll_delay_on_the_first_node_and_leaves_no_trace(monkeypatch):
+    """MIOSQP_COOP_RUN_CAL=2: the resident grid's own poll delay is MEASURED on the first node of the search (runs of one
+    synthetic 300-iteration node each: tolerances nothing can meet, an incumbent value that keeps the epilogue from branching,
+    the solution written into a free slot) whatever the caches hold.  The search that follows equals the search with a launch
+    per node -- nodes, iterations, incumbent --, the calibration's launches and nodes appear in none of its statistics, and
+    the value it chose is within the range the candidates span."""
+    pr = problems.random_miqp(170, 260, 30, seed=2)
+    monkeypatch.setenv("MIOSQP_COOP_RUN_CAL", "2")
+    from miosqp_amd import bnb, search
+    monkeypatch.setenv("MIOSQP_COOP_RUN", "1")
+    st = dict(problems.BNB_SETTINGS, device_tree=False)
+    mdl = bnb.MIOSQP()
+    mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], st,
+              dict(problems.QP_SETTINGS, coop=1, resident=0))
+    eng = mdl.work.solver
+    launch_nap = eng.factor_stats()["coop_nap"]
+    hs = search.HostedSearch(mdl)
+    eng.loop_stats(reset=True)
+    calls = 0
+    while hs.nodes < 200:
+        calls += 1
+        if hs.step(200 - hs.nodes) == 0:
+            break
+    nap, cal_nodes = eng.resident_grid_poll_delay()
+    assert cal_nodes >= 8 and launch_nap - 5 <= nap <= launch_nap + 3, (nap, launch_nap, cal_nodes)
+    assert eng.loop_launches() == calls and eng.loop_stats()[1] == hs.iters and eng.node_stats()[3] == hs.nodes
+    a = dict(nodes=hs.nodes, iters=hs.iters, open=hs._open, upper=float(mdl.work.upper_glob),
+             x=None if mdl.work.x is None else np.array(mdl.work.x, dtype=float))
+    eng.close()
+    monkeypatch.delenv("MIOSQP_COOP_RUN_CAL")
+    b = _search(pr, 1, False, monkeypatch, max_nodes=200)
+    _same(a, b)
