@@ -3,7 +3,7 @@ import sys, time, numpy as np
 sys.path.insert(0, '/root/repo')
 from miosqp_amd import qp, problems, bnb
 pr = problems.random_miqp(**problems.CONFIGS['cfg2'], seed=0)
-st = dict(problems.BNB_SETTINGS); st['max_iter_bb'] = 150
+st = dict(problems.BNB_SETTINGS, device_search=False, device_tree=False); st['max_iter_bb'] = 150  # (the Python loop: solve_node per node)
 m = bnb.MIOSQP(); m.setup(pr['P'], pr['q'], pr['A'], pr['l'], pr['u'], pr['i_idx'], pr['i_l'], pr['i_u'], st, dict(problems.QP_SETTINGS))
 eng = m.work.solver
 calls = []
