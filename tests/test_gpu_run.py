@@ -170,3 +170,56 @@ def test_resident_run_calibrates_its_poll_delay_on_the_first_node_and_leaves_no_
     monkeypatch.delenv("MIOSQP_COOP_RUN_CAL")
     b = _search(pr, 1, False, monkeypatch, max_nodes=200)
     _same(a, b)
+
+
+def test_two_resident_searches_of_one_process_take_turns_on_one_chip(monkeypatch):
+    """Two "ranks" as host threads of ONE process (miosqp_amd/poolcomm.py), each with an engine of its own on the same GPU and
+    the leaf-sharded hosted search (dist.ShardedStream over search.HostedSearch): both engines keep their cooperative grid
+    RESIDENT over their search_run calls although they share the chip -- a resident run is one whole-chip launch like any
+    other and holds its turn for the call (host_search.inc: run_possible) --, nothing is called off, the launches were
+    ordered behind each other, and the tree closes with the optimum of the sequential search.  (The multi-rank GPU tests that
+    use separate processes on one device cannot run the headline's kernel: two processes' grids never become co-resident.)"""
+    import threading
+    from miosqp_amd import bnb, dist, poolcomm, search
+    monkeypatch.delenv("MIOSQP_COOP_RUN", raising=False)
+    pr = problems.random_miqp(120, 200, 60, seed=3)
+    st = dict(problems.BNB_SETTINGS, device_tree=False, max_iter_bb=10 ** 6)
+    qs = dict(problems.QP_SETTINGS, coop=1, resident=0)
+    seq = bnb.MIOSQP()
+    seq.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st), dict(qs))
+    r0 = seq.solve()
+    seq.work.solver.close()
+    world = 2
+    tw = poolcomm.PoolWorld(world)
+    out, err = [None] * world, []
+
+    def body(rank):
+        try:
+            m = bnb.MIOSQP()
+            m.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"], dict(st), dict(qs))
+            eng = m.work.solver
+            hs = search.HostedSearch(m, capacity=1024)
+            sh = dist.ShardedStream(m, poolcomm.PoolComm(tw, rank), search=hs, step_kwargs=dict(nodes=6), exchange_every=1,
+                                    ramp_leaves=1, feed=4)
+            sh.run()
+            fs = eng.factor_stats()
+            out[rank] = dict(upper=float(m.work.upper_glob), x=np.array(m.work.x), status=m.work.status, local=hs.nodes,
+                             resident=fs["search_grid_resident"], coop=fs["coop"], fallbacks=fs["coop_fallbacks"],
+                             users=eng.chip_turn_users(), waits=eng.chip_turn_waits(), launches=eng.loop_launches())
+            eng.close()
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+            tw.fail(e)
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not err, err
+    for o in out:
+        assert o["status"] == bnb.MI_SOLVED and o["coop"] and o["resident"] and o["fallbacks"] == 0, o
+        assert o["upper"] == out[0]["upper"]
+        assert abs(o["upper"] - r0.upper_glob) <= 1e-3 * max(1.0, abs(r0.upper_glob))
+        np.testing.assert_array_equal(np.round(o["x"][pr["i_idx"]]), np.round(r0.x[pr["i_idx"]]))
+        # a launch per CALL of the search (a few nodes each), not per node
+        assert o["local"] == 0 or o["launches"] < o["local"], o
+    assert max(o["waits"] for o in out) > 0 and all(o["local"] > 0 for o in out), out
