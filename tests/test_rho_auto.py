@@ -152,3 +152,41 @@ def test_config2_tree_with_rho_chosen_at_setup():
     assert abs(out[0.1][1] - out["auto"][1]) <= 1e-3 * max(1.0, abs(out[0.1][1]))
     np.testing.assert_array_equal(out[0.1][2], out["auto"][2])
     assert out["auto"][3] * 2 <= out[0.1][3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,p,seed", [(300, 500, 150, 3), (500, 1000, 250, 0)])
+def test_probing_on_the_engine_being_set_up_equals_two_set_ups(n, m, p, seed, monkeypatch):
+    """rho="auto" on problems large enough for the inline path (n + M > 400): the probing iterations on the engine being set
+    up, the factor's dense part rebuilt in place at the chosen rho (engine.hip: probe_inline) against the r04 way -- a
+    throw-away engine for the probing, then a second whole set-up (MIOSQP_RHO_TWO_SETUPS=1): the same rho, and iterates that
+    agree to 1e-9 (the rebuilt factor reuses the first one's rows: explicit zeros of A come out +0.0 instead of -0.0, nothing
+    else differs).  ADVICE r5."""
+    from miosqp_amd import qp
+    pr = problems.random_miqp(n, m, p, seed=seed)
+    A, l, u = problems.extended(pr)
+    M = A.shape[0]
+    st = dict(problems.QP_SETTINGS, rho="auto")
+    a = qp.OSQP()
+    a.setup(pr["P"], pr["q"], A, l, u, **st)
+    monkeypatch.setenv("MIOSQP_RHO_TWO_SETUPS", "1")
+    b = qp.OSQP()
+    b.setup(pr["P"], pr["q"], A, l, u, **st)
+    monkeypatch.delenv("MIOSQP_RHO_TWO_SETUPS")
+    assert a.rho() == b.rho() != 0.1
+    rng = np.random.RandomState(seed)
+    x0, y0 = 0.1 * rng.randn(n), 0.1 * rng.randn(M)
+
+    def rel(v, w):
+        return np.max(np.abs(v - w)) / max(1.0, np.max(np.abs(w)))
+
+    for k in (1, 27, 75):
+        a.warm_start(x=x0, y=y0)
+        b.warm_start(x=x0, y=y0)
+        for va, vb in zip(a.debug_iterate(k), b.debug_iterate(k)):
+            assert rel(va, vb) <= 1e-9, k
+    a.warm_start(x=x0, y=y0)
+    b.warm_start(x=x0, y=y0)
+    ra, rb = a.solve(), b.solve()
+    assert (ra.info.status_val, ra.info.iter) == (rb.info.status_val, rb.info.iter)
+    assert rel(ra.x, rb.x) <= 1e-8 and rel(ra.y, rb.y) <= 1e-8
