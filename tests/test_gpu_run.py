@@ -223,3 +223,25 @@ def test_two_resident_searches_of_one_process_take_turns_on_one_chip(monkeypatch
         # a launch per CALL of the search (a few nodes each), not per node
         assert o["local"] == 0 or o["launches"] < o["local"], o
     assert max(o["waits"] for o in out) > 0 and all(o["local"] > 0 for o in out), out
+
+
+def test_leaf_with_inverted_integer_bounds_is_refused_where_the_host_may_read_them():
+    """add_leaf with host vectors (numpy: memory the runtime does not know, or knows as host memory) checks l <= u on the host,
+    as update(l, u) does for the reference (/root/reference/miosqp/node.py:102 -> osqp's "Lower bound must be lower than or
+    equal to upper bound"); device tensors are never dereferenced on the host (host.inc: host_may_read -- ADVICE r5: the check
+    used to run whenever the runtime did not say "device", which a tensor of another runtime instance would not)."""
+    from miosqp_amd import bnb, search
+    pr = problems.random_miqp(60, 120, 30, seed=11)
+    mdl = bnb.MIOSQP()
+    mdl.setup(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"], pr["i_idx"], pr["i_l"], pr["i_u"],
+              dict(problems.BNB_SETTINGS, device_tree=False), dict(problems.QP_SETTINGS, resident=0))
+    hs = search.HostedSearch(mdl)
+    hs.begin_instance(seed_root=False)
+    root = mdl.work._make_root()
+    lo, hi = root.l[-30:].copy(), root.u[-30:].copy()
+    lo[3], hi[3] = 1.0, 0.0
+    with pytest.raises(ValueError):
+        hs.add_leaf(lo, hi, np.zeros(60), np.zeros(150), 0, -np.inf)
+    hs.add_leaf(root.l[-30:], root.u[-30:], np.zeros(60), np.zeros(150), 0, -np.inf)
+    assert hs.step(1) >= 0 and hs.nodes == 1
+    mdl.work.solver.close()
