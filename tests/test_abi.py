@@ -88,9 +88,16 @@ def test_cooperative_exchange_loop_has_no_register_spills():
     # the loop of the headline (config 2: 3 columns per thread, testers, the grid RESIDENT over a search_run call --
     # coop_grid_run, the function the resident kernel calls per node): spill-free
     # (and coop_grid_one, the same grid in a launch of its own: solve / solve_node / a node of a search on a called-off run)
-    for fn in ("coop_grid_runILi512ELi8ELi3ELi4E", "coop_grid_oneILi512ELi8ELi3ELi4E"):
+    import re
+    for fn, max_instr in (("coop_grid_runILi512ELi8ELi3ELi4E", 520), ("coop_grid_oneILi512ELi8ELi3ELi4E", 430)):
         head = [ln for ln in r.stdout.splitlines() if fn in ln]
         assert head and "scratch accesses 0," in head[0], head
+        # ... within its register budget with room to spare (256 per lane at two waves per SIMD), and no longer than it was
+        # when it was measured (r06: 482 / 397 instructions, 230 / 228 registers): a change to the loop shows here before
+        # it shows on a GPU
+        vg = int(re.search(r"vector registers of the function (\d+)", head[0]).group(1))
+        ins = int(re.search(r"instructions in the loop (\d+)", head[0]).group(1))
+        assert 0 < vg <= 240 and 0 < ins <= max_instr, (fn, vg, ins)
 
 
 def test_every_environment_switch_is_documented():

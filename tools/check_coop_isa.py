@@ -114,7 +114,19 @@ def loops(asm):
         # THE invariant: between a poll load (global_load_dwordx4 ... sc1, inline asm) and the s_waitcnt vmcnt(0) that
         # follows it, no scratch access -- a spill there would store a register whose data has not arrived
         hazard = poll_hazards(body)
-        out.append((name, len(body), sum("scratch_" in l for l in body), sum("v_readlane" in l for l in body), hazard))
+        # the function's own vector registers (".set <name>.num_vgpr, max(N, <callees>)" behind its end: N) and the loop's
+        # INSTRUCTIONS (labels, directives and comments are not counted): a change that looks neutral in the source shows here
+        # first -- r06: a constant read inside the loop instead of before it was +20 instructions and 0.1 us per iteration
+        vg = -1
+        for l in L[e:e + 40]:
+            m = re.match(r"^\s*\.set\s+\S*" + re.escape(name.lstrip("_")) + r"\.num_vgpr,\s*(?:max\()?(\d+)", l) or \
+                re.match(r"^\s*\.set\s+\S*\.num_vgpr,\s*(?:max\()?(\d+)", l)
+            if m:
+                vg = int(m.group(1))
+                break
+        instr = sum(1 for l in body if l.split(";")[0].strip() and not l.split(";")[0].strip().startswith(".")
+                    and not l.split(";")[0].strip().endswith(":"))
+        out.append((name, len(body), sum("scratch_" in l for l in body), sum("v_readlane" in l for l in body), hazard, vg, instr))
     return out
 
 
@@ -126,9 +138,9 @@ def main():
                                "--cuda-device-only", "-w", "engine.hip", "-o", asm], cwd=src)
         res = loops(open(asm).read())
     bad = 0
-    for name, lines, scratch, readlane, hazard in res:
-        print("%s: exchange loop %d lines, scratch accesses %d, v_readlane %d, instructions between a poll and its wait that touch its registers (or scratch) %d"
-              % (name, lines, scratch, readlane, hazard))
+    for name, lines, scratch, readlane, hazard, vg, instr in res:
+        print("%s: exchange loop %d lines, scratch accesses %d, v_readlane %d, instructions between a poll and its wait that touch its registers (or scratch) %d, "
+              "vector registers of the function %d, instructions in the loop %d" % (name, lines, scratch, readlane, hazard, vg, instr))
         bad += hazard
         # (scratch accesses elsewhere in the loop cost time, not correctness: reported, and kept at zero for the layout of the
         #  headline -- 3 columns per thread, testers -- by tests/test_abi.py)
